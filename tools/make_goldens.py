@@ -1,0 +1,326 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own modules
+(read-only at /root/reference) on seeded synthetic inputs and OUR seeded weights.
+
+Runs only in the build container (the reference never travels to the GPU box).  What is
+committed is data: inputs, expected outputs, sampled elements — never reference source.
+
+Reference modules imported: evals/models/ibot_transformers.py,
+evals/models/probes.py, evals/utils/losses.py, evals/utils/optim.py — behind stub
+``evals`` / ``evals.models`` / ``evals.utils`` packages because the shipped
+``evals/models/__init__.py`` re-exports names that no longer exist.
+
+    python tools/make_goldens.py            # writes tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MVP_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+from oracle import probes as oprobes  # noqa: E402  (weight generators only)
+from oracle import train as otrain  # noqa: E402
+from oracle import vit as ovit  # noqa: E402
+
+
+def _load_reference():
+    sys.path.insert(0, REF)
+    for name, sub in (("evals", "evals"), ("evals.models", "evals/models"), ("evals.utils", "evals/utils")):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, sub)]
+        sys.modules[name] = m
+    vt = importlib.import_module("evals.models.ibot_transformers")
+    pr = importlib.import_module("evals.models.probes")
+    ls = importlib.import_module("evals.utils.losses")
+    op = importlib.import_module("evals.utils.optim")
+    return vt, pr, ls, op
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _ref_vit_taps(vt, model, images, layers, add_norm=True, patch=16):
+    """Drive the reference VisionTransformer the way DINO.forward does (dino.py:164-210):
+    the wrapper itself needs torchvision (absent), so its ~25 lines of glue are replayed
+    here around the reference's own prepare_tokens / Block / nn.BatchNorm1d."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    _, _, h, w = images.shape
+    dh, dw = h % patch, w % patch
+    if not (dh == 0 and dw == 0):
+        ph, pw = patch - dh, patch - dw
+        images = F.pad(images, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    h, w = images.shape[-2] // patch, images.shape[-1] // patch
+    bns = nn.ModuleList([nn.BatchNorm1d(model.embed_dim) for _ in layers])
+    x = model.prepare_tokens(images)
+    tokens0 = x.clone()
+    embeds = []
+    for i, blk in enumerate(model.blocks):
+        x = blk(x)
+        if i in layers:
+            if add_norm:
+                embeds.append(bns[list(layers).index(i)](x.permute(0, 2, 1)).permute(0, 2, 1))
+            else:
+                embeds.append(x)
+            if len(embeds) == len(layers):
+                break
+    outs = []
+    for e in embeds:
+        sp = e[:, -h * w:]
+        outs.append(sp.reshape(sp.shape[0], h, w, -1).permute(0, 3, 1, 2).contiguous())
+    running = [(bn.running_mean.clone(), bn.running_var.clone()) for bn in bns]
+    return tokens0, outs, running
+
+
+def golden_vit_tiny(vt):
+    """G1: tiny ViT, full tensors, non-square ragged input (pad + pos-embed interp)."""
+    cfg = dict(embed_dim=64, depth=4, num_heads=4, patch_size=16)
+    sd = ovit.make_vit_weights(embed_dim=64, depth=4, seed=11)
+    model = vt.VisionTransformer(qkv_bias=True, mlp_ratio=4, **cfg).eval()
+    missing = model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for tag, shape in (("a", (3, 3, 64, 96)), ("b", (2, 3, 70, 100)), ("c", (2, 3, 224, 224))):
+        images = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            tok, taps, running = _ref_vit_taps(vt, model, images, [0, 1, 2, 3])
+            _, raw, _ = _ref_vit_taps(vt, model, images, [3], add_norm=False)
+        out[f"{tag}_images"] = _np(images)
+        out[f"{tag}_tokens0"] = _np(tok)
+        for i, t in enumerate(taps):
+            out[f"{tag}_tap{i}"] = _np(t)
+            out[f"{tag}_rmean{i}"] = _np(running[i][0])
+            out[f"{tag}_rvar{i}"] = _np(running[i][1])
+        out[f"{tag}_raw_last"] = _np(raw[0])
+    np.savez_compressed(os.path.join(OUT, "vit_tiny.npz"), **out)
+    print("vit_tiny", {k: v.shape for k, v in out.items() if k.startswith("a_")})
+
+
+def golden_vit_base(vt):
+    """G2: ViT-B/16, weights regenerated from seed on the test side; store sampled
+    elements + moments of every tap (full tensors would be ~19 MB per case)."""
+    sd = ovit.make_vit_weights(seed=0)
+    model = vt.vit_base(patch_size=16).eval()
+    model.load_state_dict(sd, strict=True)
+    out = {}
+    for tag, (B, H, W), seed in (("b224", (2, 224, 224), 21), ("b480x640", (1, 480, 640), 22)):
+        images = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(seed))
+        with torch.no_grad():
+            tok, taps, running = _ref_vit_taps(vt, model, images, [2, 5, 8, 11])
+            _, raw, _ = _ref_vit_taps(vt, model, images, [2, 5, 8, 11], add_norm=False)
+        gi = torch.Generator().manual_seed(99)
+        out[f"{tag}_seed"] = np.array([seed, B, H, W])
+        for i, (t, r) in enumerate(zip(taps, raw)):
+            idx = torch.randint(0, t.numel(), (4096,), generator=gi)
+            out[f"{tag}_idx{i}"] = _np(idx)
+            out[f"{tag}_tap{i}_samples"] = _np(t.flatten()[idx])
+            out[f"{tag}_raw{i}_samples"] = _np(r.flatten()[idx])
+            out[f"{tag}_tap{i}_moments"] = np.array([t.mean().item(), t.std().item(), t.abs().max().item(), t.norm().item()])
+            out[f"{tag}_raw{i}_moments"] = np.array([r.mean().item(), r.std().item(), r.abs().max().item(), r.norm().item()])
+            out[f"{tag}_rmean{i}"] = _np(running[i][0])
+            out[f"{tag}_rvar{i}"] = _np(running[i][1])
+        print("vit_base", tag, [tuple(t.shape) for t in taps])
+    np.savez_compressed(os.path.join(OUT, "vit_base.npz"), **out)
+
+
+def _grads(module):
+    return {n: _np(p.grad) for n, p in module.named_parameters()}
+
+
+def golden_probes(pr):
+    """G3: every DepthHead / SurfaceNormalHead variant on tiny dims: outputs + param grads."""
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    B, C, h, w = 2, 24, 5, 7
+    vit_feats = [torch.randn(B, C, h, w, generator=g) for _ in range(4)]
+    out["vit_feats"] = np.stack([_np(f) for f in vit_feats])
+    # ResNet-style pyramid (taps at 8x,4x,2x,1x of the coarsest map, DPT bilinear x2 chain)
+    rdims = [(8, 0), (12, 0), (16, 0), (20, 0)]
+    res_feats = [torch.randn(B, rdims[i][0], 3 * 2 ** (3 - i), 4 * 2 ** (3 - i), generator=g) for i in range(4)]
+    for i, f in enumerate(res_feats):
+        out[f"res_feat{i}"] = _np(f)
+
+    cases = []
+    for k in (1, 3):
+        for pt in ("bindepth", "sigdepth"):
+            cases.append((f"depth_linear_k{k}_{pt}", "depth", dict(head_type="linear", kernel_size=k, prediction_type=pt), "vit"))
+    cases.append(("depth_dpt_k3_bindepth", "depth", dict(head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=16), "vit"))
+    cases.append(("depth_dpt_k3_sigdepth_res", "depth", dict(head_type="dpt", kernel_size=3, prediction_type="sigdepth", hidden_dim=16), "res"))
+    cases.append(("snorm_linear_k1_ua", "snorm", dict(head_type="linear", kernel_size=1, uncertainty_aware=True), "vit"))
+    cases.append(("snorm_dpt_k3_ua", "snorm", dict(head_type="dpt", kernel_size=3, uncertainty_aware=True, hidden_dim=16), "vit"))
+    cases.append(("snorm_dpt_k3_res", "snorm", dict(head_type="dpt", kernel_size=3, uncertainty_aware=False, hidden_dim=16), "res"))
+
+    for name, kind, kw, src in cases:
+        feat_dim = [C] * 4 if src == "vit" else [tuple(d) for d in rdims]
+        feats = vit_feats if src == "vit" else res_feats
+        if kind == "depth":
+            probe = pr.DepthHead(feat_dim=feat_dim, min_depth=0.001, max_depth=10, **kw)
+        else:
+            probe = pr.SurfaceNormalHead(feat_dim=feat_dim, **kw)
+        # deterministic weights: ours, through the reference key layout
+        gen = oprobes.make_linear_head_weights if kw["head_type"] == "linear" else None
+        odim = probe.head.conv.out_channels if kw["head_type"] == "linear" else probe.head.out_conv[2].out_channels
+        if kw["head_type"] == "linear":
+            sd = oprobes.make_linear_head_weights([C] * 4, odim, kw["kernel_size"], seed=17)
+        else:
+            sd = oprobes.make_dpt_weights(feat_dim, odim, hidden=16, k=kw["kernel_size"], seed=17)
+        probe.load_state_dict(sd, strict=True)
+        y = probe([f.clone() for f in feats])
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(23))
+        (y * gy).sum().backward()
+        out[f"{name}__out"] = _np(y)
+        out[f"{name}__gy"] = _np(gy)
+        out[f"{name}__name"] = np.array(probe.name)
+        for n, gr in _grads(probe).items():
+            out[f"{name}__grad__{n}"] = gr
+        print("probe", name, tuple(y.shape), probe.name)
+    np.savez_compressed(os.path.join(OUT, "probes.npz"), **out)
+
+
+def golden_losses(ls):
+    """G4: DepthLoss (B in {1,2,3,5,8,16} pins quirk Q1), sig_loss, gradient_loss,
+    angular_loss (UA on/off): values + input grads."""
+    out = {}
+    for B in (1, 2, 3, 5, 8, 16):
+        g = torch.Generator().manual_seed(100 + B)
+        pred = (torch.rand(B, 1, 12, 10, generator=g) * 9 + 0.01).requires_grad_(True)
+        tgt = torch.rand(B, 1, 12, 10, generator=g) * 12  # some > max_depth=10 -> zeroed
+        tgt[torch.rand(B, 1, 12, 10, generator=g) < 0.15] = 0
+        t_in = tgt.clone()
+        loss = ls.DepthLoss()(pred, tgt)
+        loss.backward()
+        out[f"depth_B{B}_pred"] = _np(pred)
+        out[f"depth_B{B}_target"] = _np(t_in)
+        out[f"depth_B{B}_target_after"] = _np(tgt)
+        out[f"depth_B{B}_loss"] = np.array(loss.item())
+        out[f"depth_B{B}_grad"] = _np(pred.grad)
+        with torch.no_grad():
+            out[f"depth_B{B}_sig"] = np.array(ls.sig_loss(pred, tgt).item())
+            out[f"depth_B{B}_gradloss"] = np.array(float(ls.gradient_loss(pred, tgt)))
+    for ua in (False, True):
+        g = torch.Generator().manual_seed(200 + int(ua))
+        C = 4 if ua else 3
+        pred = torch.randn(3, C, 9, 11, generator=g).requires_grad_(True)
+        gt = torch.randn(3, 3, 9, 11, generator=g)
+        gt = gt / gt.norm(dim=1, keepdim=True)
+        mask = torch.rand(3, 1, 9, 11, generator=g) > 0.2
+        loss = ls.angular_loss(pred, gt, mask, uncertainty_aware=ua)
+        loss.backward()
+        tag = f"ang_ua{int(ua)}"
+        out[f"{tag}_pred"], out[f"{tag}_gt"], out[f"{tag}_mask"] = _np(pred), _np(gt), _np(mask)
+        out[f"{tag}_loss"], out[f"{tag}_grad"] = np.array(loss.item()), _np(pred.grad)
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+    print("losses", len(out))
+
+
+def golden_optim(op, pr, ls):
+    """G5 schedule table + G6 5-step AdamW trajectory of a linear bindepth probe."""
+    import torch.nn.functional as F
+
+    out = {}
+    steps = np.arange(0, 101)
+    out["sched_steps"] = steps
+    out["sched_vals"] = np.array([op.cosine_decay_linear_warmup(int(s), 100, 15) for s in steps], dtype=np.float64)
+    out["sched_vals_frac"] = np.array([op.cosine_decay_linear_warmup(int(s), 10 * 7, 1.5 * 7) for s in range(0, 70)], dtype=np.float64)
+
+    C, B, h, w = 16, 4, 4, 5
+    probe = pr.DepthHead(feat_dim=[C] * 4, head_type="linear", kernel_size=1, prediction_type="bindepth", min_depth=0.001, max_depth=10)
+    probe.load_state_dict(oprobes.make_linear_head_weights([C] * 4, 256, 1, seed=5), strict=True)
+    optimizer = torch.optim.AdamW([{"params": probe.parameters(), "lr": 5e-4}])
+    sched = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda e: op.cosine_decay_linear_warmup(e, 40, 3))
+    loss_fn = ls.DepthLoss()
+    traj, lrs = [], []
+    for s in range(5):
+        g = torch.Generator().manual_seed(300 + s)
+        feats = [torch.randn(B, C, h, w, generator=g) for _ in range(4)]
+        tgt = torch.rand(B, 1, 4 * h + 3, 4 * w + 2, generator=g) * 9.9 + 0.05
+        tgt[torch.rand(tgt.shape, generator=g) < 0.1] = 0
+        out[f"traj_feats{s}"] = np.stack([_np(f) for f in feats])
+        out[f"traj_target{s}"] = _np(tgt)
+        optimizer.zero_grad()
+        pred = F.interpolate(probe(feats), size=tgt.shape[-2:], mode="bilinear")
+        loss = loss_fn(pred, tgt)
+        loss.backward()
+        lrs.append(optimizer.param_groups[0]["lr"])
+        optimizer.step()
+        sched.step()
+        traj.append(loss.item())
+    out["traj_losses"] = np.array(traj)
+    out["traj_lrs"] = np.array(lrs)
+    out["traj_final_weight"] = _np(probe.head.conv.weight)
+    out["traj_final_bias"] = _np(probe.head.conv.bias)
+    np.savez_compressed(os.path.join(OUT, "optim.npz"), **out)
+    print("optim", traj, lrs)
+
+
+def golden_step(vt, pr, ls, op):
+    """End-to-end: tiny ViT -> 4 taps (train-mode BN) -> linear bindepth probe -> bilinear
+    -> DepthLoss -> backward -> AdamW, 3 steps, exactly the train_depth.py loop body."""
+    import torch.nn.functional as F
+
+    D, depth = 64, 4
+    sd = ovit.make_vit_weights(embed_dim=D, depth=depth, seed=31)
+    model = vt.VisionTransformer(qkv_bias=True, mlp_ratio=4, embed_dim=D, depth=depth, num_heads=4, patch_size=16).eval()
+    model.load_state_dict(sd, strict=True)
+    probe = pr.DepthHead(feat_dim=[D] * 4, head_type="linear", kernel_size=1, prediction_type="bindepth")
+    probe.load_state_dict(oprobes.make_linear_head_weights([D] * 4, 256, 1, seed=32), strict=True)
+    optimizer = torch.optim.AdamW([{"params": probe.parameters(), "lr": 5e-4}])
+    sched = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda e: op.cosine_decay_linear_warmup(e, 30, 2))
+    loss_fn = ls.DepthLoss()
+    out = {}
+    losses = []
+    for s in range(3):
+        images, tgt = otrain.synthetic_depth_batch(4, 64, 80, rank=0, step=s)
+        optimizer.zero_grad()
+        with torch.no_grad():
+            _, feats, _ = _ref_vit_taps(vt, model, images, [0, 1, 2, 3])
+            feats = [f.detach() for f in feats]
+        pred = F.interpolate(probe(feats), size=tgt.shape[-2:], mode="bilinear")
+        loss = loss_fn(pred, tgt)
+        loss.backward()
+        if s == 0:
+            out["grad_w0"] = _np(probe.head.conv.weight.grad)
+            out["grad_b0"] = _np(probe.head.conv.bias.grad)
+            out["pred0"] = _np(pred)
+        optimizer.step()
+        sched.step()
+        losses.append(loss.item())
+    out["losses"] = np.array(losses)
+    out["final_weight"] = _np(probe.head.conv.weight)
+    out["final_bias"] = _np(probe.head.conv.bias)
+    np.savez_compressed(os.path.join(OUT, "step_tiny.npz"), **out)
+    print("step_tiny", losses)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    vt, pr, ls, op = _load_reference()
+    which = sys.argv[1:] or ["vit_tiny", "vit_base", "probes", "losses", "optim", "step"]
+    if "vit_tiny" in which:
+        golden_vit_tiny(vt)
+    if "probes" in which:
+        golden_probes(pr)
+    if "losses" in which:
+        golden_losses(ls)
+    if "optim" in which:
+        golden_optim(op, pr, ls)
+    if "step" in which:
+        golden_step(vt, pr, ls, op)
+    if "vit_base" in which:
+        golden_vit_base(vt)
+
+
+if __name__ == "__main__":
+    main()
