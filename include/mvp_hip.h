@@ -1,0 +1,304 @@
+/*
+ * mvp_hip.h — C ABI of libmvp_hip.so: the MI355X (gfx950) kernels behind the
+ * midvision-probe feature-extraction + probe-training hot path.
+ *
+ * Conventions (SURVEY.md §8b "Lower" boundary):
+ *   - every entry point is  extern "C" int mvp_<op>(const mvp_<op>_args*, void* hip_stream)
+ *     returning 0 on success or a negative MVP_E* code; nothing throws, nothing exits;
+ *   - plain pointers and sizes only (no torch types); all pointers are DEVICE pointers
+ *     unless a field says "host";
+ *   - the caller allocates every buffer, including workspaces (sizes documented per op);
+ *   - kernels are enqueued asynchronously on the stream passed in; no hidden syncs, no
+ *     allocation, no global mutable state  => safe under hipGraph capture, re-entrant
+ *     across streams and devices;
+ *   - "bf16 pair" = two uint16 bf16 arrays (hi, lo) with value = hi + lo.  With
+ *     precision MVP_PREC_BF16 only hi is read/written (lo pointers may be NULL); with
+ *     MVP_PREC_BF16X3 contractions run as hi*hi + hi*lo + lo*hi on the bf16 MFMA pipe
+ *     with fp32 accumulation (~2^-16 relative operand error, needed for the reference's
+ *     1e-3 feature-parity bar).
+ *
+ * Each op cites the reference interface (file:line under the upstream repo) it replaces.
+ */
+#ifndef MVP_HIP_H
+#define MVP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVP_OK 0
+#define MVP_EINVAL (-1)   /* bad argument (shape / alignment / NULL) */
+#define MVP_ELAUNCH (-2)  /* hipLaunch failed */
+#define MVP_ENODEV (-3)   /* no gfx950 device */
+
+#define MVP_PREC_BF16 1   /* one bf16 MFMA pass                              */
+#define MVP_PREC_BF16X3 3 /* three passes (split bf16), ~fp32 operand accuracy */
+
+#define MVP_ACT_NONE 0
+#define MVP_ACT_GELU 1 /* exact erf GELU (torch nn.GELU default)            */
+#define MVP_ACT_RELU 2
+
+typedef uint16_t mvp_bf16;
+
+/* Library / device introspection. Returns MVP_OK and fills the fields. */
+typedef struct {
+  int abi_version;      /* = MVP_ABI_VERSION                                 */
+  int device_count;     /* visible HIP devices (0 on a CPU-only box)         */
+  int gfx950;           /* 1 if device 0 is gfx950                           */
+  int cu_count;         /* multiProcessorCount of device 0                   */
+  char arch[64];        /* gcnArchName of device 0                           */
+} mvp_info_t;
+#define MVP_ABI_VERSION 1
+int mvp_get_info(mvp_info_t* out);
+const char* mvp_strerror(int code);
+
+/* ------------------------------------------------------------------------------------
+ * Elementwise split:  fp32 [n] -> bf16 pair.  Used once per frozen-weight tensor.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src;
+  mvp_bf16* hi;
+  mvp_bf16* lo; /* may be NULL */
+  int64_t n;
+} mvp_split_bf16_args;
+int mvp_split_bf16(const mvp_split_bf16_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Patch gather (im2col) for the 16x16/16 patch-embed conv.
+ * Replaces the data movement inside nn.Conv2d(3,768,16,16) of
+ * evals/models/ibot_transformers.py:216-222 (PatchEmbed.proj) and center_padding
+ * (evals/models/utils.py:55-72): zero padding (pad_top/pad_left) is applied on the fly.
+ * out row (b*gh*gw + py*gw + px), col (c*P*P + ky*P + kx)  — matches weight.view(768,-1).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* images; /* [B,C,H,W] fp32 NCHW                                  */
+  mvp_bf16* out_hi;    /* [B*gh*gw, C*P*P]                                      */
+  mvp_bf16* out_lo;    /* or NULL                                              */
+  int B, C, H, W;      /* un-padded image dims                                 */
+  int P;               /* patch size (16); must be a multiple of 4             */
+  int gh, gw;          /* patch grid after padding                             */
+  int pad_top, pad_left;
+} mvp_patch_gather_args;
+int mvp_patch_gather(const mvp_patch_gather_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:   Y = act(A · Wᵀ + bias) + residual
+ *   A  [M, K]  bf16 pair, row stride lda;   W  [N, K]  bf16 pair (torch Linear layout),
+ *   row stride ldw;  K % 64 == 0;  fp32 accumulation on the bf16 MFMA pipe.
+ * Replaces nn.Linear / 1x1 conv call sites: ibot_transformers.py:124,143 (qkv, proj),
+ * :95-106 (fc1+GELU+fc2), :216-222 (patch-embed as GEMM), probes.py:352-355,420-432.
+ * Output rows can be remapped (patch-embed writes token rows behind the CLS slot):
+ *   out_row(m) = (m / row_group) * row_group_stride + row_group_off + (m % row_group)
+ * when row_group > 0; residual row = m % res_row_mod when res_row_mod > 0 (pos-embed),
+ * else the (remapped) output row.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const mvp_bf16* a_hi; const mvp_bf16* a_lo;
+  const mvp_bf16* w_hi; const mvp_bf16* w_lo;
+  const float* bias;      /* [N] or NULL                                        */
+  const float* residual;  /* fp32, row stride ldr, or NULL                      */
+  float* out_f32;         /* row stride ldo, or NULL                            */
+  mvp_bf16* out_hi;       /* row stride ldob, or NULL                           */
+  mvp_bf16* out_lo;       /* or NULL                                            */
+  int M, N, K;
+  int lda, ldw, ldr, ldo, ldob;
+  int act;                /* MVP_ACT_*                                          */
+  int precision;          /* MVP_PREC_*                                         */
+  int row_group, row_group_stride, row_group_off, res_row_mod;
+} mvp_gemm_args;
+int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm forward: fp32 rows [M, C] -> bf16 pair [M, C] (the next GEMM's A operand).
+ * Replaces nn.LayerNorm(eps=1e-6) at ibot_transformers.py:164,174,194,199 (eps 1e-12 for
+ * the HF ViT-MAE path, evals/models/mae.py:33).  One wave64 per row, two-pass in registers.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x; const float* gamma; const float* beta;
+  mvp_bf16* out_hi; mvp_bf16* out_lo; /* lo may be NULL */
+  float* out_f32;                     /* optional fp32 copy, or NULL */
+  int M, C;                           /* C % 4 == 0, C <= 2048 */
+  float eps;
+} mvp_layernorm_args;
+int mvp_layernorm_fwd(const mvp_layernorm_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-head self-attention forward, flash-style (no N x N materialisation):
+ *   O = softmax(Q Kᵀ * scale) V   per (batch, head), head_dim = 64.
+ * qkv is the fused projection output [B*N, 3*H*64] (bf16 pair) laid out as the reference
+ * reshapes it: col = which*H*64 + head*64 + d  (ibot_transformers.py:129-142).
+ * out [B*N, H*64] bf16 pair = (attn @ v).transpose(1,2).reshape(B,N,C)  (:142).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const mvp_bf16* qkv_hi; const mvp_bf16* qkv_lo;
+  mvp_bf16* out_hi; mvp_bf16* out_lo;
+  int B, N, H;      /* tokens per image N (incl. CLS), heads H; head_dim fixed 64 */
+  int ld_qkv, ld_out;
+  float scale;      /* head_dim^-0.5 */
+  int precision;
+} mvp_attention_args;
+int mvp_attention_fwd(const mvp_attention_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * CLS row writer: x[b, 0, :] = cls[:] + pos[0, :]   (ibot_transformers.py:347-352).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* cls; const float* pos0; float* x; int B, N, C;
+} mvp_cls_rows_args;
+int mvp_cls_rows(const mvp_cls_rows_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tap BatchNorm over tokens (train-mode batch statistics, CLS included) fused with the
+ * token -> NCHW dense-map transpose.  Replaces nn.BatchNorm1d on x.permute(0,2,1)
+ * (evals/models/dino.py:185-191) + tokens_to_output("dense") (evals/models/utils.py:111-114).
+ *   stats pass : per-channel mean / biased var over all B*N rows -> stats[2*C] (mean, var),
+ *                running stats updated with momentum & unbiased var when running_* != NULL;
+ *   apply pass : y = (x - mean) * rsqrt(var + eps) * gamma + beta, spatial tokens only
+ *                (the last hw tokens of each image), written as
+ *                  nchw   [B, C, h, w] fp32          (the reference's return value)
+ *                  tok_hi/lo [B*hw (ld_tok)] bf16 pair at column offset col_off
+ *                           (token-major operand of the probe-head GEMM; optional)
+ *                  tokT_hi/lo [C rows at row offset col_off][ldT] bf16 pair
+ *                           (transposed copy, operand of the head's dW GEMM; optional)
+ * mode: 0 = train (batch stats), 1 = eval (use running stats), 2 = no norm (identity).
+ * workspace: ws_bytes = mvp_bn_tokens_workspace_bytes(M, C) (fp32 partials).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x;       /* [B, N, C] fp32 token stream                           */
+  const float* gamma; const float* beta; /* [C] or NULL (identity)               */
+  float* running_mean; float* running_var; /* [C] or NULL                        */
+  float* stats;         /* [2*C] out: batch mean, biased var                      */
+  float* nchw;          /* [B, C, hw] or NULL                                     */
+  mvp_bf16* tok_hi; mvp_bf16* tok_lo; int ld_tok; int col_off;
+  mvp_bf16* tokT_hi; mvp_bf16* tokT_lo; int ldT;
+  void* workspace; int64_t workspace_bytes;
+  int B, N, C, hw;      /* hw = spatial tokens per image (N - hw leading tokens dropped) */
+  float eps, momentum;
+  int mode;
+} mvp_bn_tokens_args;
+int64_t mvp_bn_tokens_workspace_bytes(int M, int C);
+int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * NCHW fp32 feature maps -> token-major bf16 pair (+ transposed copy).  Fallback packer
+ * used when the probe is handed plain NCHW tensors (e.g. features loaded from disk).
+ * Replaces torch.cat(feats, dim=1) of probes.py:427-429 as an operand-layout change.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* nchw;    /* [B, C, hw]                                             */
+  mvp_bf16* tok_hi; mvp_bf16* tok_lo; int ld_tok; int col_off;
+  mvp_bf16* tokT_hi; mvp_bf16* tokT_lo; int ldT;
+  int B, C, hw;
+} mvp_pack_nchw_args;
+int mvp_pack_nchw_tokens(const mvp_pack_nchw_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilinear / bicubic / nearest resampling of NCHW-like planes, forward and adjoint.
+ * Replaces F.interpolate(..., mode=..., align_corners=False|True) at
+ * train_depth.py:114 (bilinear), train_snorm.py:110 (bicubic), probes.py:255-258,388,396-398.
+ * Coordinates follow ATen's area_pixel_compute_source_index; bicubic uses A = -0.75 with
+ * clamped taps.  planes = B*C.  bwd computes grad_in[planes, Hi, Wi] (gather form, no atomics).
+ * channels_last = 1 treats the tensor as [B, H, W, C] (token-major logits), planes = B.
+ * ---------------------------------------------------------------------------------- */
+#define MVP_RESIZE_NEAREST 0
+#define MVP_RESIZE_BILINEAR 1
+#define MVP_RESIZE_BICUBIC 2
+typedef struct {
+  const float* src; float* dst;
+  int planes, Hi, Wi, Ho, Wo;
+  int mode; int align_corners;
+  int channels_last; int C; /* C used only when channels_last */
+  float scale_h, scale_w;   /* >0: the scale_factor given by the caller (recompute_scale_factor=False semantics); 0: derive from sizes */
+} mvp_resize_args;
+int mvp_resize_fwd(const mvp_resize_args*, void* stream);
+int mvp_resize_bwd(const mvp_resize_args*, void* stream); /* src = grad_out [.,Ho,Wo], dst = grad_in [.,Hi,Wi] */
+
+/* ------------------------------------------------------------------------------------
+ * Depth predictors on token-major logits [P, K] (P = B*H*W pixels, K channels contiguous).
+ *   bins   : p = relu(l) + 0.1; p /= sum(p); depth = sum_k p_k * linspace(min,max,K)[k]
+ *            (probes.py:176-200);  saves inv_sum[P] for the backward.
+ *   sigmoid: depth = min + sigmoid(l) * (max - min)          (probes.py:209-212), K == 1.
+ * bwd: grad_logits[P,K] from grad_depth[P].
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* logits; float* depth; float* inv_sum;
+  const float* grad_depth; float* grad_logits;
+  int64_t P; int K;
+  float min_depth, max_depth;
+  int kind; /* 0 = bins, 1 = sigmoid */
+} mvp_depth_predict_args;
+int mvp_depth_predict_fwd(const mvp_depth_predict_args*, void* stream);
+int mvp_depth_predict_bwd(const mvp_depth_predict_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DepthLoss = 10 * sig_loss + 0.5 * gradient_loss  (evals/utils/losses.py:97-154),
+ * including the reference's quirks: target > max_depth is zeroed IN PLACE (Q2) and the
+ * "gradient" term differences samples b and b+2 over batch strides {1,2,4,6} (Q1).
+ * pred/target [B, HW] fp32.  Outputs: loss[0] (total), loss[1] sig, loss[2] grad term;
+ * grad_pred [B, HW] = d loss / d pred (already scaled by the 10 / 0.5 weights).
+ * workspace >= mvp_depth_loss_workspace_bytes(B, HW) bytes, zero-initialised by the op.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* pred; float* target; float* loss; float* grad_pred;
+  void* workspace; int64_t workspace_bytes;
+  int B; int64_t HW;
+  float w_sig, w_grad, max_depth, eps, sigma;
+} mvp_depth_loss_args;
+int64_t mvp_depth_loss_workspace_bytes(int B, int64_t HW);
+int mvp_depth_loss_fwd_bwd(const mvp_depth_loss_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * angular_loss (evals/utils/losses.py:157-182), optional uncertainty-aware (4-channel).
+ * pred [B, Cp, HW], gt [B, 3, HW], mask [B, HW] (uint8, non-zero = valid).
+ * loss[0] = masked mean; grad_pred = d loss / d pred.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* pred; const float* gt; const uint8_t* mask;
+  float* loss; float* grad_pred;
+  void* workspace; int64_t workspace_bytes; /* >= 4096 bytes */
+  int B; int Cp; int64_t HW;
+  float eps;
+} mvp_angular_loss_args;
+int mvp_angular_loss_fwd_bwd(const mvp_angular_loss_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Column sums of a fp32 matrix [M, N] -> out[N] (bias gradients).  out is overwritten.
+ * ---------------------------------------------------------------------------------- */
+typedef struct { const float* x; float* out; int M, N, ld; } mvp_colsum_args;
+int mvp_colsum(const mvp_colsum_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused AdamW over a flat fp32 parameter buffer (torch.optim.AdamW defaults,
+ * train_depth.py:624-627): decoupled weight decay, bias correction, eps outside sqrt.
+ * lr / step are read from DEVICE scalars so the op is graph-capturable:
+ *   hyper[0] = lr, hyper[1] = 1 - beta1^t, hyper[2] = 1 - beta2^t.
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+  const float* hyper; int64_t n;
+  float beta1, beta2, eps, weight_decay, grad_scale;
+} mvp_adamw_args;
+int mvp_adamw_step(const mvp_adamw_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * SPair correspondence core (evaluate_spair_correspondence.py:59-83 + argmax_2d,
+ * evals/utils/correspondence.py:179-190): L2-normalise features over C, bilinearly sample
+ * the source map at K keypoints (grid_sample align_corners=True), cosine heat-map against
+ * the target map, 2-D argmax.  out_xy [K,2] int64 = (col,row), out_val [K] fp32.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src_feat; const float* tgt_feat; /* [C, h, w] fp32 each            */
+  const float* kp_xy;                            /* [K,2] normalised coords in [-1,1] (x,y) */
+  int64_t* out_xy; float* out_val;
+  float* workspace; int64_t workspace_bytes;    /* >= (2*h*w + K*C) * 4            */
+  int C, h, w, K;
+} mvp_corr_argmax_args;
+int mvp_corr_argmax(const mvp_corr_argmax_args*, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVP_HIP_H */

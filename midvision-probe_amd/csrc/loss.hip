@@ -1,0 +1,299 @@
+// Training losses with analytic gradients, deterministic reductions (per-block fp64 partials
+// combined in a fixed order; no float atomics):
+//   DepthLoss   = 10*sig_loss + 0.5*gradient_loss   (evals/utils/losses.py:54-74,97-154)
+//   angular_loss (optionally uncertainty-aware)      (evals/utils/losses.py:157-182)
+// Reference quirks are reproduced on purpose: target > max_depth is zeroed in place (Q2); the
+// "gradient" term pairs batch entries j and j+2 of the stride-{1,2,4,6} sub-batches (Q1).
+#include "mvp_common.h"
+
+namespace {
+
+constexpr int DL_NCH = 32;   // chunks per image in the statistics pass
+constexpr int DL_NCH2 = 64;  // chunks in the pair pass
+constexpr int DL_SCAL = 16;  // fp64 scalars
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  // deterministic: wave shuffle tree then fixed-order sum over the 4 waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct DLWs {
+  float* ld;       // [B*HW]
+  double* partA;   // [B][DL_NCH][3]
+  double* partB;   // [DL_NCH2][4]
+  double* scal;    // [DL_SCAL]
+};
+
+__device__ __host__ inline DLWs dl_ws(void* ws, int B, int64_t HW) {
+  DLWs w;
+  char* base = (char*)ws;
+  int64_t off = ((int64_t)B * HW * 4 + 15) & ~(int64_t)15;
+  w.ld = (float*)base;
+  w.partA = (double*)(base + off);
+  w.partB = w.partA + (int64_t)B * DL_NCH * 3;
+  w.scal = w.partB + DL_NCH2 * 4;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void dl_stats_kernel(const mvp_depth_loss_args p) {
+  __shared__ double red[4];
+  const DLWs w = dl_ws(p.workspace, p.B, p.HW);
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int64_t per = (p.HW + DL_NCH - 1) / DL_NCH;
+  const int64_t i0 = ch * per, i1 = min(p.HW, i0 + per);
+  double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const int64_t o = (int64_t)b * p.HW + i;
+    float t = p.target[o];
+    if (t > p.max_depth) {
+      t = 0.f;
+      p.target[o] = 0.f;
+    }
+    float g = 0.f;
+    if (t > 0.f) {
+      g = logf(p.pred[o] + p.eps) - logf(t + p.eps);
+      cnt += 1.0;
+    }
+    w.ld[o] = g;
+    s1 += (double)g;
+    s2 += (double)g * (double)g;
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  cnt = block_sum(cnt, red);
+  if (threadIdx.x == 0) {
+    double* o = w.partA + ((int64_t)b * DL_NCH + ch) * 3;
+    o[0] = s1; o[1] = s2; o[2] = cnt;
+  }
+}
+
+__device__ __forceinline__ int dl_stride(int k) { return k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 4 : 6)); }
+
+__global__ __launch_bounds__(256) void dl_pairs_kernel(const mvp_depth_loss_args p) {
+  __shared__ double red[4];
+  const DLWs w = dl_ws(p.workspace, p.B, p.HW);
+  const int64_t per = (p.HW + DL_NCH2 - 1) / DL_NCH2;
+  const int64_t i0 = blockIdx.x * per, i1 = min(p.HW, i0 + per);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int s = dl_stride(k);
+      float a = 0.f;
+      for (int b1 = 0; b1 + 2 * s < p.B; b1 += s) {
+        const int64_t o1 = (int64_t)b1 * p.HW + i, o2 = (int64_t)(b1 + 2 * s) * p.HW + i;
+        if (p.target[o1] > 0.f && p.target[o2] > 0.f) a += fabsf(w.ld[o1] - w.ld[o2]);
+      }
+      acc[k] += (double)a;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double v = block_sum(acc[k], red);
+    if (threadIdx.x == 0) w.partB[blockIdx.x * 4 + k] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dl_finalize_kernel(const mvp_depth_loss_args p) {
+  __shared__ double red[4];
+  __shared__ double cntb[1024];
+  const DLWs w = dl_ws(p.workspace, p.B, p.HW);
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < p.B * DL_NCH; i += 256) {
+    s1 += w.partA[i * 3];
+    s2 += w.partA[i * 3 + 1];
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    double c = 0.0;
+    for (int ch = 0; ch < DL_NCH; ++ch) c += w.partA[((int64_t)b * DL_NCH + ch) * 3 + 2];
+    cntb[b] = c;
+  }
+  double pr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < DL_NCH2; i += 256) a += w.partB[i * 4 + k];
+    pr[k] = block_sum(a, red);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double n = 0.0;
+    for (int b = 0; b < p.B; ++b) n += cntb[b];
+    const double mean = s1 / n;
+    const double ls = sqrt(s2 / n - (double)p.sigma * mean * mean);
+    double lg = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      const int s = dl_stride(k);
+      double ns = 0.0;
+      for (int b = 0; b < p.B; b += s) ns += cntb[b];
+      lg += pr[k] / ns;  // 0/0 -> NaN exactly like the reference when a sub-batch has no valid pixel
+      w.scal[4 + k] = (double)p.w_grad / ns;
+    }
+    p.loss[0] = (float)((double)p.w_sig * ls + (double)p.w_grad * lg);
+    p.loss[1] = (float)ls;
+    p.loss[2] = (float)lg;
+    w.scal[0] = (double)p.w_sig / (ls * n);                               // coefficient of g
+    w.scal[1] = (double)p.w_sig * (double)p.sigma * s1 / (ls * n * n);    // constant term
+  }
+}
+
+__global__ __launch_bounds__(256) void dl_grad_kernel(const mvp_depth_loss_args p) {
+  const DLWs w = dl_ws(p.workspace, p.B, p.HW);
+  const float c1 = (float)w.scal[0], c2 = (float)w.scal[1];
+  float invn[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) invn[k] = (float)w.scal[4 + k];
+  const int64_t total = (int64_t)p.B * p.HW;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    float out = 0.f;
+    if (p.target[o] > 0.f) {
+      const int b = (int)(o / p.HW);
+      const float g = w.ld[o];
+      float acc = c1 * g - c2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int s = dl_stride(k);
+        if (b % s) continue;
+        float sg = 0.f;
+        if (b - 2 * s >= 0) {
+          const int64_t o2 = o - (int64_t)2 * s * p.HW;
+          if (p.target[o2] > 0.f) { const float d = g - w.ld[o2]; sg += (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        }
+        if (b + 2 * s < p.B) {
+          const int64_t o2 = o + (int64_t)2 * s * p.HW;
+          if (p.target[o2] > 0.f) { const float d = g - w.ld[o2]; sg += (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
+        }
+        acc += invn[k] * sg;
+      }
+      out = acc / (p.pred[o] + p.eps);
+    }
+    p.grad_pred[o] = out;
+  }
+}
+
+// ----------------------------------------------------------------------------- angular loss
+constexpr int AL_NB = 128;
+
+struct AngPix { float loss; float g[4]; };
+
+__device__ __forceinline__ AngPix ang_pixel(const mvp_angular_loss_args& p, int64_t b, int64_t i, bool want_grad) {
+  AngPix r;
+  const float* pr = p.pred + (b * p.Cp) * p.HW + i;
+  const float* gt = p.gt + (b * 3) * p.HW + i;
+  const float p0 = pr[0], p1 = pr[p.HW], p2 = pr[2 * p.HW];
+  const float g0 = gt[0], g1 = gt[p.HW], g2 = gt[2 * p.HW];
+  const float np = fmaxf(sqrtf(p0 * p0 + p1 * p1 + p2 * p2), 1e-8f);
+  const float ng = fmaxf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2), 1e-8f);
+  const float ph0 = p0 / np, ph1 = p1 / np, ph2 = p2 / np;
+  const float gh0 = g0 / ng, gh1 = g1 / ng, gh2 = g2 / ng;
+  const float cosv = ph0 * gh0 + ph1 * gh1 + ph2 * gh2;
+  const float lo = -1.f + p.eps, hi = 1.f - p.eps;
+  const bool clamped = (cosv < lo) || (cosv > hi);
+  const float cc = fminf(fmaxf(cosv, lo), hi);
+  const float ang = acosf(cc);
+  float dang = clamped ? 0.f : -1.0f / sqrtf(1.f - cc * cc);  // d ang / d cos
+  float kappa = 1.f;
+  r.g[3] = 0.f;
+  if (p.Cp == 4) {
+    const float p3 = pr[3 * p.HW];
+    kappa = (p3 > 0.f ? p3 : expm1f(p3)) + 1.01f;
+    const float e = expf(-kappa * 3.14159265358979323846f);
+    r.loss = log1pf(e) - logf(kappa * kappa + 1.f) + kappa * ang;
+    if (want_grad) {
+      const float dk = -3.14159265358979323846f * e / (1.f + e) - 2.f * kappa / (kappa * kappa + 1.f) + ang;
+      r.g[3] = dk * (p3 > 0.f ? 1.f : expf(p3));
+    }
+  } else {
+    r.loss = ang;
+  }
+  if (want_grad) {
+    const float c = kappa * dang / np;
+    r.g[0] = c * (gh0 - cosv * ph0);
+    r.g[1] = c * (gh1 - cosv * ph1);
+    r.g[2] = c * (gh2 - cosv * ph2);
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(256) void ang_stats_kernel(const mvp_angular_loss_args p, double* part) {
+  __shared__ double red[4];
+  const int64_t total = (int64_t)p.B * p.HW;
+  double s = 0.0, c = 0.0;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)AL_NB * 256) {
+    if (p.mask[o]) {
+      s += (double)ang_pixel(p, o / p.HW, o % p.HW, false).loss;
+      c += 1.0;
+    }
+  }
+  s = block_sum(s, red);
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) { part[blockIdx.x * 2] = s; part[blockIdx.x * 2 + 1] = c; }
+}
+
+__global__ void ang_finalize_kernel(const mvp_angular_loss_args p, double* part) {
+  if (threadIdx.x != 0) return;
+  double s = 0.0, c = 0.0;
+  for (int i = 0; i < AL_NB; ++i) { s += part[i * 2]; c += part[i * 2 + 1]; }
+  p.loss[0] = (float)(s / c);
+  part[AL_NB * 2] = 1.0 / c;
+}
+
+__global__ __launch_bounds__(256) void ang_grad_kernel(const mvp_angular_loss_args p, const double* part) {
+  const float invn = (float)part[AL_NB * 2];
+  const int64_t total = (int64_t)p.B * p.HW;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int64_t b = o / p.HW, i = o % p.HW;
+    float* g = p.grad_pred + (b * p.Cp) * p.HW + i;
+    if (p.mask[o]) {
+      const AngPix r = ang_pixel(p, b, i, true);
+      for (int c = 0; c < p.Cp; ++c) g[c * p.HW] = r.g[c] * invn;
+    } else {
+      for (int c = 0; c < p.Cp; ++c) g[c * p.HW] = 0.f;
+    }
+  }
+}
+
+inline int grid_for(int64_t work) {
+  int64_t g = (work + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int64_t mvp_depth_loss_workspace_bytes(int B, int64_t HW) {
+  const int64_t ld = ((int64_t)B * HW * 4 + 15) & ~(int64_t)15;
+  return ld + ((int64_t)B * DL_NCH * 3 + DL_NCH2 * 4 + DL_SCAL) * 8;
+}
+
+extern "C" int mvp_depth_loss_fwd_bwd(const mvp_depth_loss_args* a, void* stream) {
+  if (!a || !a->pred || !a->target || !a->loss || !a->workspace) return MVP_EINVAL;
+  if (a->B <= 0 || a->B > 1024 || a->HW <= 0) return MVP_EINVAL;
+  if (a->workspace_bytes < mvp_depth_loss_workspace_bytes(a->B, a->HW)) return MVP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dl_stats_kernel, dim3(DL_NCH, a->B), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(dl_pairs_kernel, dim3(DL_NCH2), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(dl_finalize_kernel, dim3(1), dim3(256), 0, s, *a);
+  if (a->grad_pred) hipLaunchKernelGGL(dl_grad_kernel, dim3(grid_for((int64_t)a->B * a->HW)), dim3(256), 0, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_angular_loss_fwd_bwd(const mvp_angular_loss_args* a, void* stream) {
+  if (!a || !a->pred || !a->gt || !a->mask || !a->loss || !a->workspace) return MVP_EINVAL;
+  if (a->B <= 0 || a->HW <= 0 || (a->Cp != 3 && a->Cp != 4)) return MVP_EINVAL;
+  if (a->workspace_bytes < (int64_t)(AL_NB * 2 + 2) * 8) return MVP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  double* part = (double*)a->workspace;
+  hipLaunchKernelGGL(ang_stats_kernel, dim3(AL_NB), dim3(256), 0, s, *a, part);
+  hipLaunchKernelGGL(ang_finalize_kernel, dim3(1), dim3(64), 0, s, *a, part);
+  if (a->grad_pred) hipLaunchKernelGGL(ang_grad_kernel, dim3(grid_for((int64_t)a->B * a->HW)), dim3(256), 0, s, *a, part);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}

@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 kernels (wave64, bf16 pair arithmetic, MFMA types).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mvp_hip.h"
+
+#define MVP_WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// fp32 -> bf16 round-to-nearest-even (v_cvt_pk_bf16_f32: NaN stays NaN).
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) {
+  return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+}
+// Split v into a bf16 pair hi + lo (lo = rne(v - hi)); |v - hi - lo| <= 2^-17 |v|.
+__device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+__device__ __forceinline__ uint32_t pack2(uint16_t a, uint16_t b) {
+  return (uint32_t)a | ((uint32_t)b << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear block id: blocks that the dispatcher deals to the
+// same XCD (id % 8 equal) get a contiguous range of logical tile ids, so neighbouring
+// tiles (shared operand panels) hit the same 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+#define MVP_LAUNCH_CHECK()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return MVP_ELAUNCH;               \
+  } while (0)

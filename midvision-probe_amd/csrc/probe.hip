@@ -1,0 +1,122 @@
+// Probe-side pointwise kernels: depth predictors (bins / sigmoid) fwd+bwd, column sums.
+#include "mvp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float bin_value(int k, int K, float lo, float hi) {
+  // torch.linspace: start + step*i for the lower half, end - step*(K-1-i) for the upper half
+  const float step = (hi - lo) / (float)(K - 1);
+  return (k < K / 2) ? lo + step * (float)k : hi - step * (float)(K - 1 - k);
+}
+
+// One wave per pixel; K logits contiguous (token-major), float4 per lane per iteration.
+__global__ __launch_bounds__(256) void depth_bins_fwd(const mvp_depth_predict_args p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t px = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (px >= p.P) return;
+  const float* l = p.logits + px * p.K;
+  float s = 0.f, d = 0.f;
+  for (int k = lane * 4; k < p.K; k += 256) {
+    const float4 v = *(const float4*)(l + k);
+    const float a = fmaxf(v.x, 0.f) + 0.1f, b = fmaxf(v.y, 0.f) + 0.1f, c = fmaxf(v.z, 0.f) + 0.1f, e = fmaxf(v.w, 0.f) + 0.1f;
+    s += (a + b) + (c + e);
+    d += a * bin_value(k, p.K, p.min_depth, p.max_depth) + b * bin_value(k + 1, p.K, p.min_depth, p.max_depth) +
+         c * bin_value(k + 2, p.K, p.min_depth, p.max_depth) + e * bin_value(k + 3, p.K, p.min_depth, p.max_depth);
+  }
+  s = wave_sum(s);
+  d = wave_sum(d);
+  if (lane == 0) {
+    const float inv = 1.0f / s;
+    p.depth[px] = d * inv;
+    if (p.inv_sum) p.inv_sum[px] = inv;
+  }
+}
+
+// d depth / d l_k = [l_k > 0] * (bin_k - depth) / sum
+__global__ __launch_bounds__(256) void depth_bins_bwd(const mvp_depth_predict_args p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t px = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (px >= p.P) return;
+  const float* l = p.logits + px * p.K;
+  float* g = p.grad_logits + px * p.K;
+  const float depth = p.depth[px];
+  const float gs = p.grad_depth[px] * p.inv_sum[px];
+  for (int k = lane * 4; k < p.K; k += 256) {
+    const float4 v = *(const float4*)(l + k);
+    float4 o;
+    o.x = v.x > 0.f ? gs * (bin_value(k, p.K, p.min_depth, p.max_depth) - depth) : 0.f;
+    o.y = v.y > 0.f ? gs * (bin_value(k + 1, p.K, p.min_depth, p.max_depth) - depth) : 0.f;
+    o.z = v.z > 0.f ? gs * (bin_value(k + 2, p.K, p.min_depth, p.max_depth) - depth) : 0.f;
+    o.w = v.w > 0.f ? gs * (bin_value(k + 3, p.K, p.min_depth, p.max_depth) - depth) : 0.f;
+    *(float4*)(g + k) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_sigmoid_fwd(const mvp_depth_predict_args p) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.P; i += (int64_t)gridDim.x * 256) {
+    const float s = 1.0f / (1.0f + expf(-p.logits[i]));
+    p.depth[i] = p.min_depth + s * (p.max_depth - p.min_depth);
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_sigmoid_bwd(const mvp_depth_predict_args p) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.P; i += (int64_t)gridDim.x * 256) {
+    const float s = 1.0f / (1.0f + expf(-p.logits[i]));
+    p.grad_logits[i] = p.grad_depth[i] * (p.max_depth - p.min_depth) * s * (1.0f - s);
+  }
+}
+
+// Column sums: block = 64 columns x 4 row groups, fixed reduction order (deterministic).
+__global__ __launch_bounds__(256) void colsum_kernel(const mvp_colsum_args p) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < p.N)
+    for (int r = rg; r < p.M; r += 4) s += p.x[(size_t)r * p.ld + c];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < p.N) p.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+inline int grid_for(int64_t work) {
+  int64_t g = (work + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int mvp_depth_predict_fwd(const mvp_depth_predict_args* a, void* stream) {
+  if (!a || !a->logits || !a->depth || a->P <= 0 || a->K <= 0) return MVP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->kind == 0) {
+    if ((a->K & 3) || a->K < 2) return MVP_EINVAL;
+    hipLaunchKernelGGL(depth_bins_fwd, dim3((unsigned)((a->P + 3) / 4)), dim3(256), 0, s, *a);
+  } else {
+    if (a->K != 1) return MVP_EINVAL;
+    hipLaunchKernelGGL(depth_sigmoid_fwd, dim3(grid_for(a->P)), dim3(256), 0, s, *a);
+  }
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_depth_predict_bwd(const mvp_depth_predict_args* a, void* stream) {
+  if (!a || !a->logits || !a->grad_depth || !a->grad_logits || a->P <= 0 || a->K <= 0) return MVP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->kind == 0) {
+    if ((a->K & 3) || !a->depth || !a->inv_sum) return MVP_EINVAL;
+    hipLaunchKernelGGL(depth_bins_bwd, dim3((unsigned)((a->P + 3) / 4)), dim3(256), 0, s, *a);
+  } else {
+    if (a->K != 1) return MVP_EINVAL;
+    hipLaunchKernelGGL(depth_sigmoid_bwd, dim3(grid_for(a->P)), dim3(256), 0, s, *a);
+  }
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_colsum(const mvp_colsum_args* a, void* stream) {
+  if (!a || !a->x || !a->out || a->M <= 0 || a->N <= 0 || a->ld < a->N) return MVP_EINVAL;
+  hipLaunchKernelGGL(colsum_kernel, dim3((a->N + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}

@@ -1,0 +1,303 @@
+// Token-stream plumbing kernels (all HBM-bound, coalesced, no atomics):
+//   split_bf16        fp32 -> bf16 pair
+//   patch_gather      NCHW image -> [patches, C*P*P] bf16 pair (im2col of the 16x16/16 conv,
+//                     zero "center padding" applied on the fly)
+//   cls_rows          x[b,0,:] = cls + pos[0]
+//   bn_tokens         train-mode BatchNorm over tokens fused with token->NCHW transpose and
+//                     the token-major bf16 packing the probe-head GEMMs consume
+//   pack_nchw_tokens  NCHW fp32 -> token-major bf16 pair (+ transposed copy)
+#include "mvp_common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- split
+__global__ __launch_bounds__(256) void split_kernel(const mvp_split_bf16_args p) {
+  const int64_t n4 = p.n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = ((const float4*)p.src)[i];
+    uint16_t h[4], l[4];
+    split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]);
+    split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+    ((u32x2_t*)p.hi)[i] = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
+    if (p.lo) ((u32x2_t*)p.lo)[i] = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (p.n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    uint16_t h, l;
+    split_bf16(p.src[i], h, l);
+    p.hi[i] = h;
+    if (p.lo) p.lo[i] = l;
+  }
+}
+
+// ----------------------------------------------------------------------------- patch gather
+__global__ __launch_bounds__(256) void patch_gather_kernel(const mvp_patch_gather_args p) {
+  const int P = p.P, PP = P * P, Kc = p.C * PP;
+  const int64_t rows = (int64_t)p.B * p.gh * p.gw;
+  const int64_t total4 = rows * (Kc >> 2);
+  const bool vec = ((p.W & 3) == 0) && ((p.pad_left & 3) == 0);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / (Kc >> 2);
+    const int col = (int)(i - row * (Kc >> 2)) << 2;
+    const int c = col / PP, rem = col - c * PP, ky = rem / P, kx = rem - ky * P;
+    const int b = (int)(row / (p.gh * p.gw));
+    const int pr = (int)(row - (int64_t)b * p.gh * p.gw);
+    const int py = pr / p.gw, px = pr - py * p.gw;
+    const int y = py * P + ky - p.pad_top;
+    const int x = px * P + kx - p.pad_left;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (y >= 0 && y < p.H) {
+      const float* src = p.images + (((size_t)b * p.C + c) * p.H + y) * p.W;
+      if (vec && x >= 0 && x + 3 < p.W) {
+        const float4 t = *(const float4*)(src + x);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (x + e >= 0 && x + e < p.W) v[e] = src[x + e];
+      }
+    }
+    uint16_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
+    const size_t o = (size_t)row * Kc + col;
+    *(u32x2_t*)(p.out_hi + o) = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
+    if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+  }
+}
+
+// ----------------------------------------------------------------------------- cls rows
+__global__ __launch_bounds__(256) void cls_rows_kernel(const mvp_cls_rows_args p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.C) return;
+  const int b = i / p.C, c = i - b * p.C;
+  p.x[(size_t)b * p.N * p.C + c] = p.cls[c] + p.pos0[c];
+}
+
+// ----------------------------------------------------------------------------- BN over tokens
+constexpr int BN_RB = 32;  // rows per partial-statistics slab
+
+// Pass 1: per 32-row slab and channel, shifted sums (shift = first row of the slab) so that
+// the later variance is free of catastrophic cancellation even when |mean| >> std.
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int C) {
+  const int r0 = blockIdx.x * BN_RB;
+  const int nr = min(BN_RB, M - r0);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float* col = x + (size_t)r0 * C + c;
+    const float shift = col[0];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nr; ++r) {
+      const float d = col[(size_t)r * C] - shift;
+      s1 += d;
+      s2 += d * d;
+    }
+    float* o = part + ((size_t)blockIdx.x * C + c) * 3;
+    o[0] = shift; o[1] = s1; o[2] = s2;
+  }
+}
+
+// Pass 2: Chan's pairwise combination of the slabs in fp64 -> mean, biased var; running
+// stats (momentum, unbiased var) and the affine scale/shift used by the apply pass.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
+                                                          float* __restrict__ ss, int M, int nslab) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int s = 0; s < nslab; ++s) {
+    const float* o = part + ((size_t)s * p.C + c) * 3;
+    const double nb = (double)min(BN_RB, M - s * BN_RB);
+    const double mb = (double)o[0] + (double)o[1] / nb;
+    const double m2b = (double)o[2] - (double)o[1] * (double)o[1] / nb;
+    const double delta = mb - mean;
+    const double nn = n + nb;
+    mean += delta * nb / nn;
+    m2 += m2b + delta * delta * n * nb / nn;
+    n = nn;
+  }
+  const double var = m2 / n;
+  p.stats[c] = (float)mean;
+  p.stats[p.C + c] = (float)var;
+  if (p.running_mean) {
+    const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
+    p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+  }
+  const float rstd = rsqrtf((float)var + p.eps);
+  const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+  ss[c] = rstd * g;
+  ss[p.C + c] = b - (float)mean * rstd * g;
+}
+
+// eval (running stats) / identity modes: scale & shift without a statistics pass.
+__global__ __launch_bounds__(256) void bn_prep_kernel(const mvp_bn_tokens_args p, float* __restrict__ ss) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.C) return;
+  if (p.mode == 2) {
+    ss[c] = 1.f; ss[p.C + c] = 0.f;
+    return;
+  }
+  const float rstd = rsqrtf(p.running_var[c] + p.eps);
+  const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+  ss[c] = rstd * g;
+  ss[p.C + c] = b - p.running_mean[c] * rstd * g;
+}
+
+// Pass 3: y = x*scale + shift on the spatial tokens; 32-token x 64-channel tiles go through
+// LDS so that both the token-major reads and the NCHW / transposed writes are coalesced.
+__global__ __launch_bounds__(256) void bn_apply_kernel(const mvp_bn_tokens_args p, const float* __restrict__ ss) {
+  __shared__ float tile[32][65];
+  const int t = threadIdx.x;
+  const int ptiles = (p.hw + 31) / 32;
+  const int b = blockIdx.x / ptiles, pt = blockIdx.x - b * ptiles;
+  const int p0 = pt * 32, c0 = blockIdx.y * 64;
+  const int tok0 = p.N - p.hw;  // leading (CLS / register) tokens are dropped
+  {
+    const int c = c0 + (t & 63);
+    const float sc = (c < p.C) ? ss[c] : 0.f, sh = (c < p.C) ? ss[p.C + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tp = i * 4 + (t >> 6), pp = p0 + tp;
+      float y = 0.f;
+      if (pp < p.hw && c < p.C) {
+        y = p.x[((size_t)b * p.N + tok0 + pp) * p.C + c] * sc + sh;
+        if (p.tok_hi) {
+          uint16_t h, l;
+          split_bf16(y, h, l);
+          const size_t o = ((size_t)b * p.hw + pp) * p.ld_tok + p.col_off + c;
+          p.tok_hi[o] = h;
+          if (p.tok_lo) p.tok_lo[o] = l;
+        }
+      }
+      tile[tp][t & 63] = y;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int cc = i * 8 + (t >> 5), tp = t & 31;
+    const int c = c0 + cc, pp = p0 + tp;
+    if (c < p.C && pp < p.hw) {
+      const float y = tile[tp][cc];
+      if (p.nchw) p.nchw[((size_t)b * p.C + c) * p.hw + pp] = y;
+      if (p.tokT_hi) {
+        uint16_t h, l;
+        split_bf16(y, h, l);
+        const size_t o = (size_t)(p.col_off + c) * p.ldT + (size_t)b * p.hw + pp;
+        p.tokT_hi[o] = h;
+        if (p.tokT_lo) p.tokT_lo[o] = l;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- pack NCHW
+__global__ __launch_bounds__(256) void pack_nchw_kernel(const mvp_pack_nchw_args p) {
+  __shared__ float tile[64][33];
+  const int t = threadIdx.x;
+  const int ptiles = (p.hw + 31) / 32;
+  const int b = blockIdx.x / ptiles, pt = blockIdx.x - b * ptiles;
+  const int p0 = pt * 32, c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int cc = i * 8 + (t >> 5), tp = t & 31;
+    const int c = c0 + cc, pp = p0 + tp;
+    float y = 0.f;
+    if (c < p.C && pp < p.hw) {
+      y = p.nchw[((size_t)b * p.C + c) * p.hw + pp];
+      if (p.tokT_hi) {
+        uint16_t h, l;
+        split_bf16(y, h, l);
+        const size_t o = (size_t)(p.col_off + c) * p.ldT + (size_t)b * p.hw + pp;
+        p.tokT_hi[o] = h;
+        if (p.tokT_lo) p.tokT_lo[o] = l;
+      }
+    }
+    tile[cc][tp] = y;
+  }
+  __syncthreads();
+  if (!p.tok_hi) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int tp = i * 4 + (t >> 6), cc = t & 63;
+    const int c = c0 + cc, pp = p0 + tp;
+    if (c < p.C && pp < p.hw) {
+      uint16_t h, l;
+      split_bf16(tile[cc][tp], h, l);
+      const size_t o = ((size_t)b * p.hw + pp) * p.ld_tok + p.col_off + c;
+      p.tok_hi[o] = h;
+      if (p.tok_lo) p.tok_lo[o] = l;
+    }
+  }
+}
+
+inline int grid_for(int64_t work, int cap = 2048) {
+  int64_t g = (work + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int mvp_split_bf16(const mvp_split_bf16_args* a, void* stream) {
+  if (!a || !a->src || !a->hi || a->n <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(split_kernel, dim3(grid_for(a->n >> 2)), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_patch_gather(const mvp_patch_gather_args* a, void* stream) {
+  if (!a || !a->images || !a->out_hi) return MVP_EINVAL;
+  if (a->P <= 0 || (a->P & 3) || a->B <= 0 || a->C <= 0) return MVP_EINVAL;
+  if (a->gh * a->P < a->H + a->pad_top || a->gw * a->P < a->W + a->pad_left) return MVP_EINVAL;
+  const int64_t total4 = (int64_t)a->B * a->gh * a->gw * ((a->C * a->P * a->P) >> 2);
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(grid_for(total4, 4096)), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_cls_rows(const mvp_cls_rows_args* a, void* stream) {
+  if (!a || !a->cls || !a->pos0 || !a->x || a->B <= 0 || a->C <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(cls_rows_kernel, dim3((a->B * a->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int64_t mvp_bn_tokens_workspace_bytes(int M, int C) {
+  const int64_t nslab = (M + BN_RB - 1) / BN_RB;
+  return (nslab * C * 3 + 2 * (int64_t)C) * 4;
+}
+
+extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stream) {
+  if (!a || !a->x || !a->workspace) return MVP_EINVAL;
+  if (a->B <= 0 || a->N <= 0 || a->C <= 0 || a->hw <= 0 || a->hw > a->N) return MVP_EINVAL;
+  const int M = a->B * a->N;
+  if (a->workspace_bytes < mvp_bn_tokens_workspace_bytes(M, a->C)) return MVP_EINVAL;
+  if (a->mode == 0 && !a->stats) return MVP_EINVAL;
+  if (a->mode == 1 && (!a->running_mean || !a->running_var)) return MVP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nslab = (M + BN_RB - 1) / BN_RB;
+  float* part = (float*)a->workspace;
+  float* ss = part + (size_t)nslab * a->C * 3;
+  if (a->mode == 0) {
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, a->x, part, M, a->C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, part, ss, M, nslab);
+  } else {
+    hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
+  }
+  if (a->nchw || a->tok_hi || a->tokT_hi) {
+    const int ptiles = (a->hw + 31) / 32;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(a->B * ptiles, (a->C + 63) / 64), dim3(256), 0, s, *a, ss);
+  }
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_pack_nchw_tokens(const mvp_pack_nchw_args* a, void* stream) {
+  if (!a || !a->nchw || (!a->tok_hi && !a->tokT_hi)) return MVP_EINVAL;
+  if (a->B <= 0 || a->C <= 0 || a->hw <= 0) return MVP_EINVAL;
+  const int ptiles = (a->hw + 31) / 32;
+  hipLaunchKernelGGL(pack_nchw_kernel, dim3(a->B * ptiles, (a->C + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}

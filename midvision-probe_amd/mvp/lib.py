@@ -1,0 +1,196 @@
+"""ctypes binding of libmvp_hip.so (C ABI declared in include/mvp_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or an op returns an error
+code, a Python exception is raised.  PyTorch is used only for device memory and streams;
+every entry point receives raw device pointers + the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmvp_hip.so")
+
+PREC_BF16 = 1
+PREC_BF16X3 = 3
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BICUBIC = 0, 1, 2
+
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_i64 = C.c_int64
+
+
+class MvpError(RuntimeError):
+    pass
+
+
+class Info(C.Structure):
+    _fields_ = [("abi_version", _i), ("device_count", _i), ("gfx950", _i), ("cu_count", _i), ("arch", C.c_char * 64)]
+
+
+class SplitArgs(C.Structure):
+    _fields_ = [("src", _vp), ("hi", _vp), ("lo", _vp), ("n", _i64)]
+
+
+class PatchGatherArgs(C.Structure):
+    _fields_ = [("images", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("C", _i), ("H", _i), ("W", _i),
+                ("P", _i), ("gh", _i), ("gw", _i), ("pad_top", _i), ("pad_left", _i)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("a_hi", _vp), ("a_lo", _vp), ("w_hi", _vp), ("w_lo", _vp), ("bias", _vp), ("residual", _vp),
+                ("out_f32", _vp), ("out_hi", _vp), ("out_lo", _vp), ("M", _i), ("N", _i), ("K", _i),
+                ("lda", _i), ("ldw", _i), ("ldr", _i), ("ldo", _i), ("ldob", _i), ("act", _i), ("precision", _i),
+                ("row_group", _i), ("row_group_stride", _i), ("row_group_off", _i), ("res_row_mod", _i)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("x", _vp), ("gamma", _vp), ("beta", _vp), ("out_hi", _vp), ("out_lo", _vp), ("out_f32", _vp),
+                ("M", _i), ("C", _i), ("eps", _f)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [("qkv_hi", _vp), ("qkv_lo", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("N", _i), ("H", _i),
+                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i)]
+
+
+class ClsRowsArgs(C.Structure):
+    _fields_ = [("cls", _vp), ("pos0", _vp), ("x", _vp), ("B", _i), ("N", _i), ("C", _i)]
+
+
+class BnTokensArgs(C.Structure):
+    _fields_ = [("x", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp), ("stats", _vp),
+                ("nchw", _vp), ("tok_hi", _vp), ("tok_lo", _vp), ("ld_tok", _i), ("col_off", _i),
+                ("tokT_hi", _vp), ("tokT_lo", _vp), ("ldT", _i),
+                ("workspace", _vp), ("workspace_bytes", _i64),
+                ("B", _i), ("N", _i), ("C", _i), ("hw", _i), ("eps", _f), ("momentum", _f), ("mode", _i)]
+
+
+class PackNchwArgs(C.Structure):
+    _fields_ = [("nchw", _vp), ("tok_hi", _vp), ("tok_lo", _vp), ("ld_tok", _i), ("col_off", _i),
+                ("tokT_hi", _vp), ("tokT_lo", _vp), ("ldT", _i), ("B", _i), ("C", _i), ("hw", _i)]
+
+
+class ResizeArgs(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("planes", _i), ("Hi", _i), ("Wi", _i), ("Ho", _i), ("Wo", _i),
+                ("mode", _i), ("align_corners", _i), ("channels_last", _i), ("C", _i), ("scale_h", _f), ("scale_w", _f)]
+
+
+class DepthPredictArgs(C.Structure):
+    _fields_ = [("logits", _vp), ("depth", _vp), ("inv_sum", _vp), ("grad_depth", _vp), ("grad_logits", _vp),
+                ("P", _i64), ("K", _i), ("min_depth", _f), ("max_depth", _f), ("kind", _i)]
+
+
+class DepthLossArgs(C.Structure):
+    _fields_ = [("pred", _vp), ("target", _vp), ("loss", _vp), ("grad_pred", _vp), ("workspace", _vp),
+                ("workspace_bytes", _i64), ("B", _i), ("HW", _i64), ("w_sig", _f), ("w_grad", _f), ("max_depth", _f),
+                ("eps", _f), ("sigma", _f)]
+
+
+class AngularLossArgs(C.Structure):
+    _fields_ = [("pred", _vp), ("gt", _vp), ("mask", _vp), ("loss", _vp), ("grad_pred", _vp), ("workspace", _vp),
+                ("workspace_bytes", _i64), ("B", _i), ("Cp", _i), ("HW", _i64), ("eps", _f)]
+
+
+class ColsumArgs(C.Structure):
+    _fields_ = [("x", _vp), ("out", _vp), ("M", _i), ("N", _i), ("ld", _i)]
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("hyper", _vp), ("n", _i64),
+                ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("grad_scale", _f)]
+
+
+class CorrArgmaxArgs(C.Structure):
+    _fields_ = [("src_feat", _vp), ("tgt_feat", _vp), ("kp_xy", _vp), ("out_xy", _vp), ("out_val", _vp),
+                ("workspace", _vp), ("workspace_bytes", _i64), ("C", _i), ("h", _i), ("w", _i), ("K", _i)]
+
+
+# every exported symbol of include/mvp_hip.h: name -> args struct (None = special signature)
+SYMBOLS = {
+    "mvp_get_info": None,
+    "mvp_strerror": None,
+    "mvp_split_bf16": SplitArgs,
+    "mvp_patch_gather": PatchGatherArgs,
+    "mvp_gemm_bias_act_res": GemmArgs,
+    "mvp_layernorm_fwd": LayerNormArgs,
+    "mvp_attention_fwd": AttentionArgs,
+    "mvp_cls_rows": ClsRowsArgs,
+    "mvp_bn_tokens_workspace_bytes": None,
+    "mvp_bn_tokens_to_nchw_fwd": BnTokensArgs,
+    "mvp_pack_nchw_tokens": PackNchwArgs,
+    "mvp_resize_fwd": ResizeArgs,
+    "mvp_resize_bwd": ResizeArgs,
+    "mvp_depth_predict_fwd": DepthPredictArgs,
+    "mvp_depth_predict_bwd": DepthPredictArgs,
+    "mvp_depth_loss_workspace_bytes": None,
+    "mvp_depth_loss_fwd_bwd": DepthLossArgs,
+    "mvp_angular_loss_fwd_bwd": AngularLossArgs,
+    "mvp_colsum": ColsumArgs,
+    "mvp_adamw_step": AdamWArgs,
+    "mvp_corr_argmax": CorrArgmaxArgs,
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmvp_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MvpError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C midvision-probe_amd/csrc`). There is no CPU fallback for the product path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, st in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        if st is not None:
+            fn.argtypes = [C.POINTER(st), _vp]
+            fn.restype = _i
+    lib.mvp_get_info.argtypes = [C.POINTER(Info)]
+    lib.mvp_get_info.restype = _i
+    lib.mvp_strerror.argtypes = [_i]
+    lib.mvp_strerror.restype = C.c_char_p
+    lib.mvp_bn_tokens_workspace_bytes.argtypes = [_i, _i]
+    lib.mvp_bn_tokens_workspace_bytes.restype = _i64
+    lib.mvp_depth_loss_workspace_bytes.argtypes = [_i, _i64]
+    lib.mvp_depth_loss_workspace_bytes.restype = _i64
+    _lib = lib
+    return lib
+
+
+def info() -> Info:
+    out = Info()
+    check(load().mvp_get_info(C.byref(out)), "mvp_get_info")
+    return out
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise MvpError(f"{what} failed: {load().mvp_strerror(code).decode()} (code {code})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MvpError("expected a device tensor (the HIP path has no CPU fallback)")
+    return t.data_ptr()
+
+
+def call(name: str, args: C.Structure) -> None:
+    check(getattr(load(), name)(C.byref(args), stream_ptr()), name)

@@ -1,0 +1,150 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point).
+
+A "pair" is a tuple ``(hi, lo)`` of torch.bfloat16 tensors with value hi + lo; ``lo`` is
+None in MVP_PREC_BF16 mode.  All tensors must live on the current HIP device; outputs are
+allocated by the caller (or by these helpers with torch.empty — plumbing only).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib
+from .lib import PREC_BF16, PREC_BF16X3
+
+Pair = Tuple[torch.Tensor, Optional[torch.Tensor]]
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise lib.MvpError(f"{name}: expected contiguous {dtype} device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def empty_pair(shape, precision: int, device) -> Pair:
+    hi = torch.empty(shape, dtype=torch.bfloat16, device=device)
+    lo = torch.empty(shape, dtype=torch.bfloat16, device=device) if precision == PREC_BF16X3 else None
+    return hi, lo
+
+
+def zeros_pair(shape, precision: int, device) -> Pair:
+    hi = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+    lo = torch.zeros(shape, dtype=torch.bfloat16, device=device) if precision == PREC_BF16X3 else None
+    return hi, lo
+
+
+def split_bf16(src: torch.Tensor, precision: int = PREC_BF16X3) -> Pair:
+    src = src.contiguous()
+    _chk(src, torch.float32, "split_bf16.src")
+    hi, lo = empty_pair(src.shape, precision, src.device)
+    a = lib.SplitArgs(lib.ptr(src), lib.ptr(hi), lib.ptr(lo), src.numel())
+    lib.call("mvp_split_bf16", a)
+    return hi, lo
+
+
+def patch_gather(images: torch.Tensor, out: Pair, P: int, gh: int, gw: int, pad_top: int, pad_left: int) -> None:
+    _chk(images, torch.float32, "patch_gather.images")
+    B, Cc, H, W = images.shape
+    a = lib.PatchGatherArgs(lib.ptr(images), lib.ptr(out[0]), lib.ptr(out[1]), B, Cc, H, W, P, gh, gw, pad_top, pad_left)
+    lib.call("mvp_patch_gather", a)
+
+
+def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, out_f32=None, out: Optional[Pair] = None,
+         act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
+         row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0) -> None:
+    """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res)."""
+    o_hi, o_lo = out if out is not None else (None, None)
+    args = lib.GemmArgs(
+        lib.ptr(a[0]), lib.ptr(a[1]), lib.ptr(w[0]), lib.ptr(w[1]), lib.ptr(bias), lib.ptr(residual),
+        lib.ptr(out_f32), lib.ptr(o_hi), lib.ptr(o_lo), M, N, K,
+        lda if lda is not None else K, ldw if ldw is not None else K,
+        ldr if ldr is not None else N, ldo if ldo is not None else N, ldob if ldob is not None else N,
+        act, precision, row_group, row_group_stride, row_group_off, res_row_mod)
+    lib.call("mvp_gemm_bias_act_res", args)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,
+              out_f32: Optional[torch.Tensor] = None) -> None:
+    a = lib.LayerNormArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(out[0]), lib.ptr(out[1]), lib.ptr(out_f32), M, Cdim, eps)
+    lib.call("mvp_layernorm_fwd", a)
+
+
+def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None) -> None:
+    a = lib.AttentionArgs(lib.ptr(qkv[0]), lib.ptr(qkv[1]), lib.ptr(out[0]), lib.ptr(out[1]), B, N, H,
+                          ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision)
+    lib.call("mvp_attention_fwd", a)
+
+
+def cls_rows(cls: torch.Tensor, pos0: torch.Tensor, x: torch.Tensor, B: int, N: int, Cdim: int) -> None:
+    lib.call("mvp_cls_rows", lib.ClsRowsArgs(lib.ptr(cls), lib.ptr(pos0), lib.ptr(x), B, N, Cdim))
+
+
+def bn_tokens_workspace_bytes(M: int, Cdim: int) -> int:
+    return int(lib.load().mvp_bn_tokens_workspace_bytes(M, Cdim))
+
+
+def bn_tokens_to_nchw(x, B, N, Cdim, hw, *, workspace, stats=None, gamma=None, beta=None, running_mean=None, running_var=None,
+                      nchw=None, tok: Optional[Pair] = None, ld_tok=0, col_off=0, tokT: Optional[Pair] = None, ldT=0,
+                      eps=1e-5, momentum=0.1, mode=0) -> None:
+    t_hi, t_lo = tok if tok is not None else (None, None)
+    tt_hi, tt_lo = tokT if tokT is not None else (None, None)
+    a = lib.BnTokensArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(running_mean), lib.ptr(running_var), lib.ptr(stats),
+                         lib.ptr(nchw), lib.ptr(t_hi), lib.ptr(t_lo), ld_tok, col_off, lib.ptr(tt_hi), lib.ptr(tt_lo), ldT,
+                         lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode)
+    lib.call("mvp_bn_tokens_to_nchw_fwd", a)
+
+
+def pack_nchw_tokens(nchw: torch.Tensor, B: int, Cdim: int, hw: int, *, tok: Optional[Pair] = None, ld_tok=0, col_off=0,
+                     tokT: Optional[Pair] = None, ldT=0) -> None:
+    t_hi, t_lo = tok if tok is not None else (None, None)
+    tt_hi, tt_lo = tokT if tokT is not None else (None, None)
+    a = lib.PackNchwArgs(lib.ptr(nchw), lib.ptr(t_hi), lib.ptr(t_lo), ld_tok, col_off, lib.ptr(tt_hi), lib.ptr(tt_lo), ldT, B, Cdim, hw)
+    lib.call("mvp_pack_nchw_tokens", a)
+
+
+def resize(src: torch.Tensor, dst: torch.Tensor, planes: int, Hi: int, Wi: int, Ho: int, Wo: int, mode: int, *, align_corners=False,
+           channels_last=False, Cdim=0, scale_h=0.0, scale_w=0.0, backward=False) -> None:
+    """forward: src [.,Hi,Wi] -> dst [.,Ho,Wo];  backward: src = grad_out [.,Ho,Wo] -> dst = grad_in [.,Hi,Wi]."""
+    a = lib.ResizeArgs(lib.ptr(src), lib.ptr(dst), planes, Hi, Wi, Ho, Wo, mode, int(align_corners), int(channels_last), Cdim, scale_h, scale_w)
+    lib.call("mvp_resize_bwd" if backward else "mvp_resize_fwd", a)
+
+
+def depth_predict_fwd(logits, depth, inv_sum, P, K, min_depth, max_depth, kind) -> None:
+    a = lib.DepthPredictArgs(lib.ptr(logits), lib.ptr(depth), lib.ptr(inv_sum), None, None, P, K, min_depth, max_depth, kind)
+    lib.call("mvp_depth_predict_fwd", a)
+
+
+def depth_predict_bwd(logits, depth, inv_sum, grad_depth, grad_logits, P, K, min_depth, max_depth, kind) -> None:
+    a = lib.DepthPredictArgs(lib.ptr(logits), lib.ptr(depth), lib.ptr(inv_sum), lib.ptr(grad_depth), lib.ptr(grad_logits), P, K, min_depth, max_depth, kind)
+    lib.call("mvp_depth_predict_bwd", a)
+
+
+def depth_loss_workspace_bytes(B: int, HW: int) -> int:
+    return int(lib.load().mvp_depth_loss_workspace_bytes(B, HW))
+
+
+def depth_loss(pred, target, loss, grad_pred, workspace, B, HW, w_sig=10.0, w_grad=0.5, max_depth=10.0, eps=1e-3, sigma=0.85) -> None:
+    a = lib.DepthLossArgs(lib.ptr(pred), lib.ptr(target), lib.ptr(loss), lib.ptr(grad_pred), lib.ptr(workspace),
+                          workspace.numel() * workspace.element_size(), B, HW, w_sig, w_grad, max_depth, eps, sigma)
+    lib.call("mvp_depth_loss_fwd_bwd", a)
+
+
+def angular_loss(pred, gt, mask_u8, loss, grad_pred, workspace, B, Cp, HW, eps=1e-4) -> None:
+    a = lib.AngularLossArgs(lib.ptr(pred), lib.ptr(gt), lib.ptr(mask_u8), lib.ptr(loss), lib.ptr(grad_pred), lib.ptr(workspace),
+                            workspace.numel() * workspace.element_size(), B, Cp, HW, eps)
+    lib.call("mvp_angular_loss_fwd_bwd", a)
+
+
+def colsum(x, out, M, N, ld=None) -> None:
+    lib.call("mvp_colsum", lib.ColsumArgs(lib.ptr(x), lib.ptr(out), M, N, ld if ld is not None else N))
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0) -> None:
+    a = lib.AdamWArgs(lib.ptr(param), lib.ptr(grad), lib.ptr(exp_avg), lib.ptr(exp_avg_sq), lib.ptr(hyper), n, beta1, beta2, eps, weight_decay, grad_scale)
+    lib.call("mvp_adamw_step", a)
+
+
+def corr_argmax(src_feat, tgt_feat, kp_xy, out_xy, out_val, workspace, Cdim, h, w, K) -> None:
+    a = lib.CorrArgmaxArgs(lib.ptr(src_feat), lib.ptr(tgt_feat), lib.ptr(kp_xy), lib.ptr(out_xy), lib.ptr(out_val), lib.ptr(workspace),
+                           workspace.numel() * workspace.element_size(), Cdim, h, w, K)
+    lib.call("mvp_corr_argmax", a)

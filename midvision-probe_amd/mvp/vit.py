@@ -1,0 +1,241 @@
+"""ViT-B/16-class frozen backbone forward on the HIP kernels (DINO / iBOT / MoCo-v3 / MAE
+share this engine; the wrappers under evals/models differ in weights, pos-embed policy,
+LayerNorm eps and which block outputs are tapped).
+
+Data layout in HBM (per batch of B images, N = 1 + gh*gw tokens, M = B*N rows):
+  x        fp32  [M, C]      residual stream (kept fp32: LN statistics and residual adds)
+  xn       bf16 pair [M, C]  LayerNorm output = A operand of the next GEMM
+  qkv      bf16 pair [M, 3C] fused projection, read in place by the attention kernel
+  ao       bf16 pair [M, C]  attention output (already in (B, N, H*64) order)
+  hmid     bf16 pair [M, 4C] fc1+GELU output
+  weights  bf16 pairs, torch Linear layout [N_out, K] (K contiguous) — split once at load.
+Everything is allocated once per (B, gh, gw) and reused: the frozen forward allocates only
+the returned NCHW maps.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import lib, ops
+from .lib import PREC_BF16, PREC_BF16X3
+
+
+def parse_precision(p) -> int:
+    if p in (PREC_BF16, PREC_BF16X3):
+        return p
+    s = str(p).lower()
+    if s in ("bf16", "fast"):
+        return PREC_BF16
+    if s in ("bf16x3", "x3", "exact", "fp32"):
+        return PREC_BF16X3
+    raise ValueError(f"unknown precision {p!r} (use 'bf16' or 'bf16x3')")
+
+
+class TapOutputs(list):
+    """The list of NCHW maps a backbone returns, plus (privately) the token-major bf16
+    packing of the same features that the probe-head GEMMs consume."""
+    packed = None
+
+
+class PackedFeatures:
+    """Token-major operand of the linear-probe GEMMs: F [Mpad, Ctot] and Fᵀ [Ctot, Mpad] bf16 pairs."""
+
+    def __init__(self, B, h, w, Ctot, precision, device):
+        self.B, self.h, self.w, self.Ctot, self.precision = B, h, w, Ctot, precision
+        self.M = B * h * w
+        self.Mpad = (self.M + 63) // 64 * 64
+        self.tok = ops.zeros_pair((self.Mpad, Ctot), precision, device)
+        self.tokT = ops.zeros_pair((Ctot, self.Mpad), precision, device)
+        self.sources: List[Tuple[int, int]] = []  # (data_ptr, _version) of the NCHW maps packed here
+
+
+_PACK_REGISTRY: Dict[int, PackedFeatures] = {}
+
+
+def register_pack(maps: Sequence[torch.Tensor], pack: PackedFeatures) -> None:
+    pack.sources = [(m.data_ptr(), m._version) for m in maps]
+    _PACK_REGISTRY.clear()  # single most-recent entry: the probe consumes features right after the backbone
+    _PACK_REGISTRY[maps[0].data_ptr()] = pack
+
+
+def lookup_pack(maps: Sequence[torch.Tensor]) -> Optional[PackedFeatures]:
+    """Return the packing produced alongside ``maps`` if these are still the very same
+    (unmodified) buffers; ``.detach()`` in the training loop keeps data_ptr and version."""
+    if not maps:
+        return None
+    pack = _PACK_REGISTRY.get(maps[0].data_ptr())
+    if pack is None or len(pack.sources) != len(maps):
+        return None
+    for m, (p, v) in zip(maps, pack.sources):
+        if m.data_ptr() != p or m._version != v:
+            return None
+    return pack
+
+
+class ViTEngine:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, heads: int, patch: int = 16, ln_eps: float = 1e-6,
+                 precision="bf16x3", device="cuda", pos_embed_mode: str = "dino", qkv_fused: bool = True):
+        self.device = torch.device(device)
+        self.precision = parse_precision(precision)
+        self.heads, self.patch, self.ln_eps = heads, patch, ln_eps
+        self.pos_embed_mode = pos_embed_mode
+        sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
+        self.C = sd["cls_token"].shape[-1]
+        if self.C != heads * 64:
+            raise lib.MvpError(f"attention kernel requires head_dim 64 (C={self.C}, heads={heads})")
+        self.depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+        self.cls = sd["cls_token"].reshape(-1).contiguous()
+        self.pos_embed = sd["pos_embed"]  # [1, 1+n, C] fp32
+        pw = sd["patch_embed.proj.weight"]
+        self.in_chans = pw.shape[1]
+        self.w_patch = ops.split_bf16(pw.reshape(self.C, -1), self.precision)
+        self.b_patch = sd["patch_embed.proj.bias"]
+        self.blocks = []
+        for i in range(self.depth):
+            p = f"blocks.{i}."
+            blk = dict(
+                n1w=sd[p + "norm1.weight"], n1b=sd[p + "norm1.bias"],
+                qkv_w=ops.split_bf16(sd[p + "attn.qkv.weight"], self.precision),
+                qkv_b=sd.get(p + "attn.qkv.bias"),
+                proj_w=ops.split_bf16(sd[p + "attn.proj.weight"], self.precision), proj_b=sd[p + "attn.proj.bias"],
+                n2w=sd[p + "norm2.weight"], n2b=sd[p + "norm2.bias"],
+                fc1_w=ops.split_bf16(sd[p + "mlp.fc1.weight"], self.precision), fc1_b=sd[p + "mlp.fc1.bias"],
+                fc2_w=ops.split_bf16(sd[p + "mlp.fc2.weight"], self.precision), fc2_b=sd[p + "mlp.fc2.bias"],
+            )
+            self.blocks.append(blk)
+        self.hidden = self.blocks[0]["fc1_b"].numel()
+        self._ws: Dict[Tuple[int, int, int], dict] = {}
+        self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, B: int, gh: int, gw: int) -> dict:
+        key = (B, gh, gw)
+        ws = self._ws.get(key)
+        if ws is None:
+            N = 1 + gh * gw
+            M = B * N
+            C, dev, pr = self.C, self.device, self.precision
+            ws = dict(
+                x=torch.empty(M, C, dtype=torch.float32, device=dev),
+                xn=ops.empty_pair((M, C), pr, dev),
+                qkv=ops.empty_pair((M, 3 * C), pr, dev),
+                ao=ops.empty_pair((M, C), pr, dev),
+                hmid=ops.empty_pair((M, self.hidden), pr, dev),
+                patches=ops.empty_pair((B * gh * gw, self.in_chans * self.patch * self.patch), pr, dev),
+                bn_ws=torch.empty(ops.bn_tokens_workspace_bytes(M, C) // 4 + 16, dtype=torch.float32, device=dev),
+            )
+            self._ws = {key: ws}  # keep one resolution resident
+        return ws
+
+    def pos_for(self, gh: int, gw: int, dim2: int, dim3: int) -> torch.Tensor:
+        """Pos-embed for a gh x gw grid.  'dino': bicubic resize with the +0.1 scale nudge of
+        ibot_transformers.py:311-336 (done once per resolution, cached; torch's bicubic on the
+        device is used for this one-time [1,C,14,14] resample)."""
+        key = (gh, gw)
+        pe = self._pos.get(key)
+        if pe is not None:
+            return pe
+        n = self.pos_embed.shape[1] - 1
+        if self.pos_embed_mode == "fixed" or (gh * gw == n and dim2 == dim3):
+            pe = self.pos_embed[0].contiguous()
+        else:
+            side = int(math.sqrt(n))
+            w0, h0 = dim2 // self.patch + 0.1, dim3 // self.patch + 0.1
+            grid = self.pos_embed[:, 1:].reshape(1, side, side, self.C).permute(0, 3, 1, 2)
+            grid = F.interpolate(grid, scale_factor=(w0 / math.sqrt(n), h0 / math.sqrt(n)), mode="bicubic")
+            assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+            pe = torch.cat((self.pos_embed[0, :1], grid.permute(0, 2, 3, 1).reshape(-1, self.C)), dim=0).contiguous()
+        self._pos[key] = pe
+        return pe
+
+    def set_pos_embed(self, pos_embed: torch.Tensor) -> None:
+        self.pos_embed = pos_embed.detach().to(self.device, torch.float32).contiguous()
+        self._pos.clear()
+
+    # ------------------------------------------------------------------ forward
+    def tokens(self, images: torch.Tensor) -> Tuple[dict, int, int, int]:
+        """Patch-embed + CLS + pos-embed into ws['x'] (K1); returns (ws, B, gh, gw)."""
+        images = images.to(self.device, torch.float32).contiguous()
+        B, Cin, H, W = images.shape
+        P = self.patch
+        rh, rw = H % P, W % P
+        if rh == 0 and rw == 0:
+            ph = pw = 0
+        else:  # center_padding quirk: a non-ragged dim still gets a full patch (utils.py:55-72)
+            ph, pw = P - rh, P - rw
+        gh, gw = (H + ph) // P, (W + pw) // P
+        ws = self._workspace(B, gh, gw)
+        N, C = 1 + gh * gw, self.C
+        ops.patch_gather(images, ws["patches"], P, gh, gw, ph // 2, pw // 2)
+        pos = self.pos_for(gh, gw, H + ph, W + pw)
+        Kp = Cin * P * P
+        # x[b, 1+p, :] = patches · Wᵀ + bias + pos[1+p]   (row remap skips the CLS slot)
+        ops.gemm(ws["patches"], self.w_patch, B * gh * gw, C, Kp, bias=self.b_patch, residual=pos[1:], out_f32=ws["x"],
+                 precision=self.precision, row_group=gh * gw, row_group_stride=N, row_group_off=1, res_row_mod=gh * gw)
+        ops.cls_rows(self.cls, pos, ws["x"], B, N, C)
+        return ws, B, gh, gw
+
+    def run_block(self, i: int, ws: dict, B: int, N: int) -> None:
+        blk, C, M, pr = self.blocks[i], self.C, B * N, self.precision
+        x = ws["x"]
+        ops.layernorm(x, blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps)
+        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=pr)
+        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr)
+        ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=pr)
+        ops.layernorm(x, blk["n2w"], blk["n2b"], ws["xn"], M, C, self.ln_eps)
+        ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=pr)
+        ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=pr)
+
+    def forward_taps(self, images: torch.Tensor, layers: Sequence[int], *, bn: Optional[Sequence[dict]] = None,
+                     bn_mode: int = 0, pack: bool = True, tap_input_of_block: bool = False) -> TapOutputs:
+        """Run blocks up to the last tapped one; at each tap apply the (train-mode) tap BN and
+        emit the NCHW map (+ token-major packing).  ``bn[j]`` = dict(weight,bias,running_mean,
+        running_var) tensors or None; bn_mode: 0 train stats, 1 eval, 2 no norm.
+        ``tap_input_of_block``: tap the INPUT of block i instead of its output (HF
+        hidden_states indexing used by the MAE wrapper, quirk Q4)."""
+        ws, B, gh, gw = self.tokens(images)
+        N, C, hw = 1 + gh * gw, self.C, gh * gw
+        layers = list(layers)
+        outs = TapOutputs()
+        packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device) if pack else None
+        stats = torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device)
+
+        def tap(j):
+            nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
+            b = bn[j] if bn is not None else None
+            ops.bn_tokens_to_nchw(
+                ws["x"], B, N, C, hw, workspace=ws["bn_ws"], stats=stats[j],
+                gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
+                running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
+                nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Ctot if packed else 0, col_off=j * C,
+                tokT=packed.tokT if packed else None, ldT=packed.Mpad if packed else 0, mode=bn_mode)
+            outs.append(nchw)
+
+        last = max(layers)
+        for i in range(self.depth):
+            if tap_input_of_block and i in layers:
+                tap(layers.index(i))
+                if len(outs) == len(layers):
+                    break
+            self.run_block(i, ws, B, N)
+            if (not tap_input_of_block) and i in layers:
+                tap(layers.index(i))
+                if len(outs) == len(layers):
+                    break
+        outs.stats = stats
+        if packed is not None:
+            outs.packed = packed
+            register_pack(outs, packed)
+        return outs
+
+    def forward_tokens(self, images: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
+        """Raw fp32 token stream after ``n_blocks`` blocks ([B, N, C]); for tests / CLS outputs."""
+        ws, B, gh, gw = self.tokens(images)
+        N = 1 + gh * gw
+        for i in range(self.depth if n_blocks is None else n_blocks):
+            self.run_block(i, ws, B, N)
+        return ws["x"].view(B, N, self.C).clone()

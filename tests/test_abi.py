@@ -1,0 +1,58 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/mvp_hip.h declares; argument validation returns error codes (no compute, no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def _declared():
+    src = open(os.path.join(REPO, "include", "mvp_hip.h")).read()
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(mvp_\w+)\s*\(", src, flags=re.M)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from mvp import lib
+
+    declared = _declared()
+    assert len(declared) >= 20
+    assert set(declared) == set(lib.SYMBOLS), set(declared) ^ set(lib.SYMBOLS)
+    so = lib.load()
+    for name in declared:
+        assert hasattr(so, name), name
+
+
+def test_info_and_strerror():
+    from mvp import lib
+
+    inf = lib.info()
+    assert inf.abi_version == 1
+    assert lib.load().mvp_strerror(-1).decode().startswith("invalid argument")
+
+
+def test_bad_arguments_return_einval():
+    """Host-side shape checks run before any launch, so they are testable without a GPU."""
+    from mvp import lib
+
+    so = lib.load()
+    a = lib.GemmArgs()  # all NULL / zero
+    assert so.mvp_gemm_bias_act_res(ctypes.byref(a), None) == -1
+    a = lib.GemmArgs(a_hi=16, w_hi=16, out_f32=16, M=4, N=4, K=48, lda=48, ldw=48, precision=1)
+    assert so.mvp_gemm_bias_act_res(ctypes.byref(a), None) == -1  # K % 64 != 0
+    b = lib.AttentionArgs(qkv_hi=16, out_hi=16, B=1, N=4, H=1, ld_qkv=100, ld_out=64, precision=1)
+    assert so.mvp_attention_fwd(ctypes.byref(b), None) == -1  # ld_qkv < 3*H*64
+    c = lib.LayerNormArgs(x=16, gamma=16, beta=16, out_hi=16, M=1, C=4098)
+    assert so.mvp_layernorm_fwd(ctypes.byref(c), None) == -1
+    assert so.mvp_bn_tokens_workspace_bytes(3152, 768) == (99 * 768 * 3 + 2 * 768) * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mvp import lib
+
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.MvpError, match="no CPU fallback"):
+        lib.load()

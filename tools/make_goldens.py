@@ -83,10 +83,12 @@ def _ref_vit_taps(vt, model, images, layers, add_norm=True, patch=16):
     return tokens0, outs, running
 
 
-def golden_vit_tiny(vt):
-    """G1: tiny ViT, full tensors, non-square ragged input (pad + pos-embed interp)."""
-    cfg = dict(embed_dim=64, depth=4, num_heads=4, patch_size=16)
-    sd = ovit.make_vit_weights(embed_dim=64, depth=4, seed=11)
+def golden_vit_tiny(vt, embed_dim=64, heads=4, fname="vit_tiny.npz"):
+    """G1: tiny ViT, full tensors, non-square ragged input (pad + pos-embed interp).
+    Two variants: 64/4 heads (head_dim 16, oracle only) and 128/2 heads (head_dim 64, the
+    HIP attention kernel's head size)."""
+    cfg = dict(embed_dim=embed_dim, depth=4, num_heads=heads, patch_size=16)
+    sd = ovit.make_vit_weights(embed_dim=embed_dim, depth=4, seed=11)
     model = vt.VisionTransformer(qkv_bias=True, mlp_ratio=4, **cfg).eval()
     missing = model.load_state_dict(sd, strict=True)
     g = torch.Generator().manual_seed(5)
@@ -103,7 +105,7 @@ def golden_vit_tiny(vt):
             out[f"{tag}_rmean{i}"] = _np(running[i][0])
             out[f"{tag}_rvar{i}"] = _np(running[i][1])
         out[f"{tag}_raw_last"] = _np(raw[0])
-    np.savez_compressed(os.path.join(OUT, "vit_tiny.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
     print("vit_tiny", {k: v.shape for k, v in out.items() if k.startswith("a_")})
 
 
@@ -307,9 +309,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     vt, pr, ls, op = _load_reference()
-    which = sys.argv[1:] or ["vit_tiny", "vit_base", "probes", "losses", "optim", "step"]
+    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step"]
     if "vit_tiny" in which:
         golden_vit_tiny(vt)
+    if "vit_tiny128" in which:
+        golden_vit_tiny(vt, embed_dim=128, heads=2, fname="vit_tiny128.npz")
     if "probes" in which:
         golden_probes(pr)
     if "losses" in which:
