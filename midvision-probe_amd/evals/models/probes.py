@@ -1,0 +1,180 @@
+"""evals.models.probes — drop-in for the reference's probe heads (evals/models/probes.py:86-459):
+same class names, constructor kwargs, ``.name`` strings and state-dict keys
+(``head.conv.weight``, ``head.conv_0.weight``, ``head.ref_0.resConfUnit1.conv.0.weight`` ...),
+forward/backward on the HIP kernels (mvp.functional).
+
+nn.Conv2d modules are kept as PARAMETER CONTAINERS only (so reference ``ckpt.pth["probe"]``
+state dicts load unchanged); their arithmetic runs in the HIP GEMM / conv kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from mvp import backbone as bb
+from mvp import functional as MF
+from mvp import lib
+from mvp.vit import parse_precision
+
+
+def _precision(p):
+    return parse_precision(p or bb.default_precision())
+
+
+class SurfaceNormalHead(nn.Module):
+    """Reference: probes.py:86-116."""
+
+    def __init__(self, feat_dim, head_type="multiscale", uncertainty_aware=False, hidden_dim=512, kernel_size=1, precision=None):
+        super().__init__()
+        self.uncertainty_aware = uncertainty_aware
+        output_dim = 4 if uncertainty_aware else 3
+        self.kernel_size = kernel_size
+        assert head_type in ["linear", "multiscale", "dpt"]
+        name = f"snorm_{head_type}_k{kernel_size}"
+        self.name = f"{name}_UA" if uncertainty_aware else name
+        if head_type == "linear":
+            self.head = Linear(feat_dim, output_dim, kernel_size, precision=precision)
+        elif head_type == "dpt":
+            self.head = DPT(feat_dim, output_dim, hidden_dim, kernel_size, precision=precision)
+        else:
+            raise NotImplementedError("multiscale head is not on the hot path (configs/probe use dpt / linear)")
+
+    def forward(self, feats):
+        return self.head(feats)
+
+
+class DepthHead(nn.Module):
+    """Reference: probes.py:119-157."""
+
+    def __init__(self, feat_dim, head_type="multiscale", min_depth=0.001, max_depth=10, prediction_type="sigdepth", hidden_dim=512,
+                 kernel_size=1, precision=None):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.name = f"{prediction_type}_{head_type}_k{kernel_size}"
+        if prediction_type == "bindepth":
+            output_dim = 256
+            self.predict = DepthBinPrediction(min_depth, max_depth, n_bins=output_dim)
+        elif prediction_type == "sigdepth":
+            output_dim = 1
+            self.predict = DepthSigmoidPrediction(min_depth, max_depth)
+        else:
+            raise ValueError()
+        if head_type == "linear":
+            self.head = Linear(feat_dim, output_dim, kernel_size, precision=precision)
+        elif head_type == "dpt":
+            self.head = DPT(feat_dim, output_dim, hidden_dim, kernel_size, precision=precision)
+        else:
+            raise NotImplementedError("multiscale head is not on the hot path (configs/probe use dpt / linear)")
+
+    def forward(self, feats):
+        """Prediction each pixel."""
+        feats = self.head(feats)
+        return self.predict(feats)
+
+
+def _as_channels_last(x: torch.Tensor) -> torch.Tensor:
+    """[B,K,H,W] (any strides) -> contiguous [B,H,W,K] without a copy when x is already a
+    permuted view of a channels-last buffer (what Linear/DPT return)."""
+    y = x.permute(0, 2, 3, 1)
+    return y if y.is_contiguous() else y.contiguous()
+
+
+class DepthBinPrediction(nn.Module):
+    """Reference: probes.py:160-200 ('UD' bins, 'linear' normalisation)."""
+
+    def __init__(self, min_depth=0.001, max_depth=10, n_bins=256, bins_strategy="UD", norm_strategy="linear"):
+        super().__init__()
+        if bins_strategy != "UD" or norm_strategy != "linear":
+            raise NotImplementedError("only the reference defaults (UD bins, linear norm) are on the hot path")
+        self.n_bins, self.min_depth, self.max_depth = n_bins, min_depth, max_depth
+        self.norm_strategy, self.bins_strategy = norm_strategy, bins_strategy
+
+    def forward(self, prob):
+        return MF.depth_bins(_as_channels_last(prob), self.n_bins, self.min_depth, self.max_depth)
+
+
+class DepthSigmoidPrediction(nn.Module):
+    """Reference: probes.py:203-212."""
+
+    def __init__(self, min_depth=0.001, max_depth=10):
+        super().__init__()
+        self.min_depth, self.max_depth = min_depth, max_depth
+
+    def forward(self, pred):
+        return MF.depth_sigmoid(_as_channels_last(pred), self.min_depth, self.max_depth)
+
+
+class Linear(nn.Module):
+    """Reference: probes.py:417-432 — cat maps, bilinear x4, conv k x k.  For k = 1 the conv
+    and the bilinear resample commute, so the GEMM runs at token resolution (16x fewer rows)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size=1, precision=None):
+        super().__init__()
+        if type(input_dim) is not int:
+            input_dim = sum(input_dim)
+        assert type(input_dim) is int
+        padding = kernel_size // 2
+        self.conv = nn.Conv2d(input_dim, output_dim, kernel_size, padding=padding)
+        self.kernel_size = kernel_size
+        self.precision = _precision(precision)
+
+    def forward(self, feats):
+        if type(feats) is not list and not isinstance(feats, (list, tuple)):
+            feats = [feats]
+        if self.kernel_size != 1:
+            raise NotImplementedError("Linear probe with kernel_size > 1 is not on the HIP path yet (k=1 is the linear-probe headline)")
+        K = self.conv.out_channels
+        lq = MF.linear_head_k1(feats, self.conv.weight, self.conv.bias, self.precision)  # [B,4h,4w,K4]
+        return lq[..., :K].permute(0, 3, 1, 2)  # NCHW view of the channels-last logits
+
+
+class DPT(nn.Module):
+    """Reference: probes.py:309-399.  Parameter layout kept; the conv stack is not yet on the
+    HIP path (round-1 scope = linear probe); constructing it is allowed so that state dicts
+    load, calling it raises."""
+
+    def __init__(self, input_dims, output_dim, hidden_dim=512, kernel_size=3, precision=None):
+        super().__init__()
+        assert len(input_dims) == 4
+        self.resnet = not isinstance(input_dims[0], int)
+        for i in range(4):
+            if self.resnet:
+                conv = nn.Conv2d(input_dims[i][0], hidden_dim, kernel_size=3, stride=1, padding=1, bias=False)
+            else:
+                conv = nn.Conv2d(input_dims[i], hidden_dim, 1, padding=0)
+            setattr(self, f"conv_{i}", conv)
+        for i in range(4):
+            setattr(self, f"ref_{i}", FeatureFusionBlock(hidden_dim, kernel_size, is_transformer=not self.resnet, with_skip=(i != 3)))
+        self.out_conv = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1), nn.ReLU(True), nn.Conv2d(hidden_dim, output_dim, 3, padding=1))
+        self.precision = _precision(precision)
+
+    def forward(self, feats):
+        assert len(feats) == 4
+        raise NotImplementedError("DPT probe forward/backward is not on the HIP path yet (see DESIGN.md, scope row P4)")
+
+
+class FeatureFusionBlock(nn.Module):
+    """Reference: probes.py:215-259 (parameter container)."""
+
+    def __init__(self, features, kernel_size=3, with_skip=True, upsample=False, is_transformer=False):
+        super().__init__()
+        self.with_skip, self.upsample, self.is_transformer = with_skip, upsample, is_transformer
+        if self.with_skip:
+            self.resConfUnit1 = ResidualConvUnit(features, kernel_size, is_transformer=is_transformer)
+        self.resConfUnit2 = ResidualConvUnit(features, kernel_size, is_transformer=is_transformer)
+
+
+class ResidualConvUnit(nn.Module):
+    """Reference: probes.py:262-306 (parameter container)."""
+
+    def __init__(self, features, kernel_size=3, is_transformer=False, inplace_relu=True):
+        super().__init__()
+        if is_transformer:
+            assert kernel_size % 2 == 1, "Kernel size needs to be odd for transformer-based implementation"
+            padding = kernel_size // 2
+            self.conv = nn.Sequential(nn.Conv2d(features, features, kernel_size, padding=padding), nn.ReLU(inplace=inplace_relu),
+                                      nn.Conv2d(features, features, kernel_size, padding=padding), nn.ReLU(inplace=inplace_relu))
+        else:
+            self.conv1 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+            self.conv2 = nn.Conv2d(features, features, kernel_size=3, stride=1, padding=1, bias=True)
+            self.relu = nn.ReLU(inplace=inplace_relu)

@@ -1,0 +1,48 @@
+"""One process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm) for rendezvous and
+the single per-step collective.  Mirrors train_depth.py:64-73 (ddp_setup) and the
+DistributedSampler sharding of evals/datasets/builder.py:50-65."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def ddp_setup(rank: int, world_size: int, port: int, backend: str = "nccl"):
+    """Reference: train_depth.py:64-73.  127.0.0.1 instead of 'localhost' (container hostnames may not resolve)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+    if backend == "nccl":
+        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
+
+
+def env_setup(backend: str = "nccl"):
+    """torchrun-style: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif backend == "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+def shard_indices(n: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):
+    """DistributedSampler semantics (builder.py:50-51, train_depth.py:94-95): permutation seeded
+    by seed+epoch, padded by wrap-around to a multiple of world, rank r takes r, r+W, ..."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed + epoch)
+        idx = torch.randperm(n, generator=g).tolist()
+    else:
+        idx = list(range(n))
+    total = (n + world - 1) // world * world
+    pad = total - len(idx)
+    if pad > 0:
+        idx += (idx * ((pad + len(idx) - 1) // len(idx)))[:pad]
+    return idx[rank:total:world]

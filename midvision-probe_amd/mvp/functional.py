@@ -1,0 +1,227 @@
+"""Autograd-visible operators of the probe path.  Each Function's forward AND backward call
+the HIP kernels through the C ABI; PyTorch only provides the tape, memory and streams.
+
+  interpolate        F.interpolate replacement (nearest / bilinear / bicubic)   train_depth.py:114, train_snorm.py:110
+  linear_head        probes.py:427-432 for kernel_size=1 (cat -> bilinear x4 -> conv1x1), evaluated as
+                     conv1x1 at token resolution then bilinear x4 (the two commute; 16x less work)
+  depth_bins / depth_sigmoid   probes.py:176-212
+  depth_loss / angular_loss    evals/utils/losses.py:97-182
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib, ops
+from .lib import PREC_BF16, PREC_BF16X3
+from .vit import PackedFeatures, lookup_pack
+
+_MODES = {"nearest": lib.RESIZE_NEAREST, "bilinear": lib.RESIZE_BILINEAR, "bicubic": lib.RESIZE_BICUBIC}
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise lib.MvpError(f"{what}: the HIP path needs device tensors (there is no CPU fallback)")
+
+
+# --------------------------------------------------------------------------- interpolate
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, mode, align, sh, sw):
+        _need_cuda(x, "interpolate")
+        x = x.contiguous().float()
+        B, C, Hi, Wi = x.shape
+        y = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=x.device)
+        ops.resize(x, y, B * C, Hi, Wi, Ho, Wo, mode, align_corners=align, scale_h=sh, scale_w=sw)
+        ctx.cfg = (B, C, Hi, Wi, Ho, Wo, mode, align, sh, sw)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C, Hi, Wi, Ho, Wo, mode, align, sh, sw = ctx.cfg
+        gy = gy.contiguous().float()
+        gx = torch.empty(B, C, Hi, Wi, dtype=torch.float32, device=gy.device)
+        ops.resize(gy, gx, B * C, Hi, Wi, Ho, Wo, mode, align_corners=align, scale_h=sh, scale_w=sw, backward=True)
+        return gx, None, None, None, None, None, None
+
+
+def interpolate(x: torch.Tensor, size=None, scale_factor=None, mode: str = "nearest", align_corners: Optional[bool] = None) -> torch.Tensor:
+    """Drop-in for torch.nn.functional.interpolate on NCHW fp32 (the modes the reference uses)."""
+    if mode not in _MODES:
+        raise NotImplementedError(f"interpolate mode {mode!r}")
+    Hi, Wi = x.shape[-2:]
+    sh = sw = 0.0
+    if size is not None:
+        Ho, Wo = (size, size) if isinstance(size, int) else tuple(int(s) for s in size)
+    else:
+        sf = (scale_factor, scale_factor) if not isinstance(scale_factor, (tuple, list)) else scale_factor
+        sh, sw = float(sf[0]), float(sf[1])
+        Ho, Wo = int(Hi * sh), int(Wi * sw)  # floor, as torch
+    return _Interpolate.apply(x, Ho, Wo, _MODES[mode], bool(align_corners), sh, sw)
+
+
+# --------------------------------------------------------------------------- linear head (k = 1)
+def pack_features(feats: Sequence[torch.Tensor], precision: int) -> PackedFeatures:
+    """Token-major bf16 operands for the head GEMMs: reuse the packing the backbone wrote next
+    to these very maps when available, else pack the NCHW tensors now."""
+    pack = lookup_pack(feats)
+    if pack is not None and pack.precision == precision:
+        return pack
+    B, _, h, w = feats[0].shape
+    for f in feats:
+        _need_cuda(f, "probe features")
+        if f.shape[0] != B or f.shape[-2:] != (h, w):
+            raise lib.MvpError("linear head: all feature maps must share batch and resolution (reference quirk Q7)")
+    Ctot = sum(int(f.shape[1]) for f in feats)
+    pack = PackedFeatures(B, h, w, Ctot, precision, feats[0].device)
+    off = 0
+    for f in feats:
+        C = int(f.shape[1])
+        ops.pack_nchw_tokens(f.contiguous().float(), B, C, h * w, tok=pack.tok, ld_tok=pack.Cpad, col_off=off, tokT=pack.tokT, ldT=pack.Mpad)
+        off += C
+    return pack
+
+
+class _LinearHeadK1(torch.autograd.Function):
+    """logits_q[B, 4h, 4w, K] (channels-last) = bilinear_x4( F · Wᵀ + b )."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, pack: PackedFeatures, precision: int):
+        K, Ctot = weight.shape[0], pack.Ctot
+        K4 = (K + 3) // 4 * 4
+        dev = weight.device
+        w2 = weight.detach().reshape(K, Ctot).float()
+        b1 = bias.detach().float()
+        if K4 != K or pack.Cpad != Ctot:
+            # pad output channels to a multiple of 4 (channels-last kernels) and K to a multiple of 64 (GEMM)
+            wpad = w2.new_zeros(K4, pack.Cpad)
+            wpad[:K, :Ctot] = w2
+            w2 = wpad
+            b1 = torch.cat([b1, b1.new_zeros(K4 - K)], 0)
+        wp = ops.split_bf16(w2.contiguous(), precision)
+        l0 = torch.empty(pack.M, K4, dtype=torch.float32, device=dev)
+        ops.gemm(pack.tok, wp, pack.M, K4, pack.Cpad, bias=b1.contiguous(), out_f32=l0, precision=precision)
+        B, h, w = pack.B, pack.h, pack.w
+        lq = torch.empty(B, 4 * h, 4 * w, K4, dtype=torch.float32, device=dev)
+        ops.resize(l0, lq, B, h, w, 4 * h, 4 * w, lib.RESIZE_BILINEAR, channels_last=True, Cdim=K4, scale_h=4.0, scale_w=4.0)
+        ctx.pack, ctx.precision, ctx.K, ctx.K4 = pack, precision, K, K4
+        ctx.wshape = weight.shape
+        return lq
+
+    @staticmethod
+    def backward(ctx, glq):
+        pack, pr, K, K4 = ctx.pack, ctx.precision, ctx.K, ctx.K4
+        B, h, w, Ctot = pack.B, pack.h, pack.w, pack.Ctot
+        dev = glq.device
+        glq = glq.contiguous()
+        gl0 = torch.empty(pack.M, K4, dtype=torch.float32, device=dev)
+        ops.resize(glq, gl0, B, h, w, 4 * h, 4 * w, lib.RESIZE_BILINEAR, channels_last=True, Cdim=K4, scale_h=4.0, scale_w=4.0, backward=True)
+        # dW[K, Ctot] = gl0ᵀ · F : both operands K-major over the (zero padded) token axis
+        gT = ops.zeros_pair((K4, pack.Mpad), pr, dev)
+        ops.pack_nchw_tokens(gl0, 1, pack.M, K4, tok=gT, ld_tok=pack.Mpad, col_off=0)
+        dW = torch.empty(K4, Ctot, dtype=torch.float32, device=dev)
+        ops.gemm(gT, pack.tokT, K4, Ctot, pack.Mpad, out_f32=dW, precision=pr)
+        db = torch.empty(K4, dtype=torch.float32, device=dev)
+        ops.colsum(gl0, db, pack.M, K4)
+        return dW[:K].reshape(ctx.wshape), db[:K], None, None
+
+
+def linear_head_k1(feats: Sequence[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, precision: int) -> torch.Tensor:
+    """Returns channels-last logits [B, 4h, 4w, K4] (K4 = K rounded up to 4; extra channels are zero)."""
+    pack = pack_features(list(feats), precision)
+    return _LinearHeadK1.apply(weight, bias, pack, precision)
+
+
+# --------------------------------------------------------------------------- depth predictors
+class _DepthPredict(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits_cl, K, min_depth, max_depth, kind):
+        B, H, W, Kp = logits_cl.shape
+        if Kp != K and not (kind == 1 and K == 1):
+            raise lib.MvpError("depth predictor: channel padding is only supported for sigmoid heads")
+        P = B * H * W
+        lg = logits_cl.contiguous()
+        if kind == 1 and Kp != 1:
+            lg = lg[..., :1].contiguous()
+        depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=lg.device)
+        inv = torch.empty(P, dtype=torch.float32, device=lg.device) if kind == 0 else None
+        ops.depth_predict_fwd(lg, depth, inv, P, K, min_depth, max_depth, kind)
+        ctx.save_for_backward(lg, depth, inv if inv is not None else depth)
+        ctx.cfg = (P, K, Kp, min_depth, max_depth, kind, logits_cl.shape)
+        return depth
+
+    @staticmethod
+    def backward(ctx, gd):
+        lg, depth, inv = ctx.saved_tensors
+        P, K, Kp, mn, mx, kind, shape = ctx.cfg
+        gl = torch.empty_like(lg)
+        ops.depth_predict_bwd(lg, depth, inv if kind == 0 else None, gd.contiguous().float(), gl, P, K, mn, mx, kind)
+        if kind == 1 and Kp != 1:
+            full = gl.new_zeros(shape)
+            full[..., :1] = gl
+            gl = full
+        return gl, None, None, None, None
+
+
+def depth_bins(logits_cl, n_bins, min_depth, max_depth):
+    return _DepthPredict.apply(logits_cl, n_bins, float(min_depth), float(max_depth), 0)
+
+
+def depth_sigmoid(logits_cl, min_depth, max_depth):
+    return _DepthPredict.apply(logits_cl, 1, float(min_depth), float(max_depth), 1)
+
+
+# --------------------------------------------------------------------------- losses
+class _DepthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, w_sig, w_grad, max_depth):
+        _need_cuda(pred, "DepthLoss")
+        if not (target.is_cuda and target.is_contiguous() and target.dtype == torch.float32):
+            raise lib.MvpError("DepthLoss: target must be a contiguous fp32 device tensor (it is modified in place, quirk Q2)")
+        B = pred.shape[0]
+        HW = pred.numel() // B
+        p = pred.contiguous().float()
+        out = torch.empty(4, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        ws = torch.empty(ops.depth_loss_workspace_bytes(B, HW) // 4 + 4, dtype=torch.float32, device=p.device)
+        ops.depth_loss(p, target, out, grad, ws, B, HW, w_sig, w_grad, max_depth)
+        ctx.save_for_backward(grad)
+        ctx.parts = out
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
+def depth_loss(pred, target, w_sig=10.0, w_grad=0.5, max_depth=10.0):
+    return _DepthLoss.apply(pred, target, float(w_sig), float(w_grad), float(max_depth))
+
+
+class _AngularLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, mask, eps):
+        _need_cuda(pred, "angular_loss")
+        B, Cp = pred.shape[:2]
+        HW = pred.numel() // (B * Cp)
+        p = pred.contiguous().float()
+        m = mask.reshape(B, -1).to(torch.uint8).contiguous()
+        out = torch.empty(4, dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        ws = torch.empty(1024, dtype=torch.float32, device=p.device)
+        ops.angular_loss(p, gt.contiguous().float(), m, out, grad, ws, B, Cp, HW, eps)
+        ctx.save_for_backward(grad)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def angular_loss(pred, gt, mask, uncertainty_aware=False, eps=1e-4):
+    assert mask.ndim == 4, f"mask should be (batch x height x width) not {mask.shape}"
+    assert pred.shape[1] == (4 if uncertainty_aware else 3)
+    return _AngularLoss.apply(pred, gt, mask, float(eps))

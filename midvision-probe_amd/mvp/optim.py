@@ -1,0 +1,97 @@
+"""Flat fused AdamW for the probe parameters (train_depth.py:624-627 uses torch.optim.AdamW
+defaults: betas (0.9, 0.999), eps 1e-8, weight_decay 0.01).
+
+All parameters are re-pointed into ONE contiguous fp32 buffer, their .grad into a second
+one: the optimiser step is a single HIP kernel over the flat buffer and the data-parallel
+gradient exchange is a single RCCL all-reduce of the flat gradient.
+It subclasses torch.optim.Optimizer so torch LR schedulers (LambdaLR, train_depth.py:636-641)
+drive ``param_groups[0]["lr"]`` exactly as they do for torch.optim.AdamW.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+from . import ops
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, process_group=None, world_size: Optional[int] = None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("FlatAdamW handles the single probe parameter group of the trainers (model_lr == 0)")
+        plist = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        if not plist:
+            raise ValueError("no trainable parameters")
+        dev = plist[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdamW needs device parameters (no CPU fallback)")
+        sizes = [(p.numel() + 3) // 4 * 4 for p in plist]  # keep every view 16-byte aligned
+        total = sum(sizes)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p, sz in zip(plist, sizes):
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[off:off + n].view(p.shape)
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+                off += sz
+        self._params = plist
+        self._n = total
+        self._step = 0
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(4)
+        self.process_group = process_group
+        self.world_size = world_size
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the flat gradient IN PLACE (the .grad views must survive: autograd accumulates into them)."""
+        self.flat_grad.zero_()
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + off * 4:
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+            off += (n + 3) // 4 * 4
+
+    def _gather_stray_grads(self):
+        """autograd replaces .grad when it was None at backward time; fold such tensors back."""
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            want = self.flat_grad.data_ptr() + off * 4
+            if p.grad is not None and p.grad.data_ptr() != want:
+                self.flat_grad[off:off + n].copy_(p.grad.reshape(-1))
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+            off += (n + 3) // 4 * 4
+
+    def all_reduce_grads(self):
+        """One collective per step: SUM over ranks of the flat fp32 gradient (RCCL over xGMI);
+        the 1/world average is folded into the AdamW kernel's grad_scale."""
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
+            return dist.get_world_size(self.process_group)
+        return 1
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._gather_stray_grads()
+        world = self.all_reduce_grads()
+        g = self.param_groups[0]
+        self._step += 1
+        b1, b2 = g["betas"]
+        self._hyper_host[0] = float(g["lr"])
+        self._hyper_host[1] = 1.0 - b1 ** self._step
+        self._hyper_host[2] = 1.0 - b2 ** self._step
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyper, self._n,
+                       beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"], grad_scale=1.0 / world)
+        return None

@@ -1,0 +1,76 @@
+"""The hot loop bodies of train_depth.py:93-144 and train_snorm.py:86-120, on the HIP path.
+
+``train_depth_step`` / ``train_snorm_step`` are the per-batch bodies (what bench.py times);
+``train`` mirrors the reference's ``train()`` signature for drop-in use.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import functional as MF
+
+
+def extract_features(model, images, detach_model=True):
+    """train_depth.py:103-112."""
+    if detach_model:
+        with torch.no_grad():
+            feats = model(images)
+            if isinstance(feats, (tuple, list)):
+                feats = [_f.detach() for _f in feats]
+            else:
+                feats = feats.detach()
+    else:
+        feats = model(images)
+    return feats
+
+
+def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model=True):
+    """One iteration of train_depth.py:99-143; returns the loss as a DEVICE scalar (the
+    reference's per-step ``loss.item()`` host sync is left to the caller)."""
+    optimizer.zero_grad()
+    feats = extract_features(model, images, detach_model)
+    pred = probe(feats)
+    pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
+    loss = loss_fn(pred, target)
+    loss.backward()
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach()
+
+
+def train_snorm_step(model, probe, optimizer, scheduler, images, target, mask, detach_model=True):
+    """One iteration of train_snorm.py:93-120 (bicubic upsample, angular loss, UA iff 4 channels)."""
+    from evals.utils.losses import angular_loss
+
+    optimizer.zero_grad()
+    feats = extract_features(model, images, detach_model)
+    pred = probe(feats)
+    pred = MF.interpolate(pred.contiguous(), size=target.shape[-2:], mode="bicubic")
+    uncertainty = pred.shape[1] > 3
+    loss = angular_loss(pred, target, mask, uncertainty_aware=uncertainty)
+    loss.backward()
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach()
+
+
+def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_model, loss_fn, rank=0, world_size=1,
+          valid_loader=None, scale_invariant=False, wandb_use=False, is_final=False, is_navi=False, log_every=0):
+    """Reference signature: train_depth.py:76-92.  Batches are dicts {"image", "depth"} (nyu.py:245-251)."""
+    if scale_invariant:
+        raise NotImplementedError("scale_invariant training (match_scale_and_shift) is outside the hot path")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    history = []
+    for ep in range(n_epochs):
+        if world_size > 1 and hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+            train_loader.sampler.set_epoch(ep)
+        train_loss = 0.0
+        for i, batch in enumerate(train_loader):
+            images = batch["image"].to(dev, non_blocking=True)
+            target = batch["depth"].to(dev, non_blocking=True).contiguous()
+            loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model)
+            train_loss += loss.item()  # the reference syncs every step too (train_depth.py:143)
+        history.append(train_loss / max(len(train_loader), 1))
+    return history

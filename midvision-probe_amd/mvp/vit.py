@@ -48,7 +48,8 @@ class PackedFeatures:
         self.B, self.h, self.w, self.Ctot, self.precision = B, h, w, Ctot, precision
         self.M = B * h * w
         self.Mpad = (self.M + 63) // 64 * 64
-        self.tok = ops.zeros_pair((self.Mpad, Ctot), precision, device)
+        self.Cpad = (Ctot + 63) // 64 * 64  # GEMM K dims are multiples of 64; pad columns stay zero
+        self.tok = ops.zeros_pair((self.Mpad, self.Cpad), precision, device)
         self.tokT = ops.zeros_pair((Ctot, self.Mpad), precision, device)
         self.sources: List[Tuple[int, int]] = []  # (data_ptr, _version) of the NCHW maps packed here
 
@@ -211,7 +212,7 @@ class ViTEngine:
                 ws["x"], B, N, C, hw, workspace=ws["bn_ws"], stats=stats[j],
                 gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                 running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
-                nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Ctot if packed else 0, col_off=j * C,
+                nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
                 tokT=packed.tokT if packed else None, ldT=packed.Mpad if packed else 0, mode=bn_mode)
             outs.append(nchw)
 

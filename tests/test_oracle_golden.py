@@ -171,10 +171,10 @@ def test_adamw_trajectory():
 def test_full_step_tiny():
     """Oracle trainer == the reference loop body (tiny ViT, 3 steps)."""
     g = load_golden("step_tiny.npz")
-    D = 64
+    D = 128
     vsd = ovit.make_vit_weights(embed_dim=D, depth=4, seed=31)
     psd = oprobes.make_linear_head_weights([D] * 4, 256, 1, seed=32)
-    tr = otrain.DepthProbeTrainer(vsd, psd, layers=(0, 1, 2, 3), heads=4, max_step=30, warmup_step=2)
+    tr = otrain.DepthProbeTrainer(vsd, psd, layers=(0, 1, 2, 3), heads=2, max_step=30, warmup_step=2)
     losses = []
     for s in range(3):
         images, tgt = otrain.synthetic_depth_batch(4, 64, 80, rank=0, step=s)

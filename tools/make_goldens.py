@@ -271,9 +271,9 @@ def golden_step(vt, pr, ls, op):
     -> DepthLoss -> backward -> AdamW, 3 steps, exactly the train_depth.py loop body."""
     import torch.nn.functional as F
 
-    D, depth = 64, 4
+    D, depth = 128, 4  # 2 heads of 64 = the HIP attention kernel's head size
     sd = ovit.make_vit_weights(embed_dim=D, depth=depth, seed=31)
-    model = vt.VisionTransformer(qkv_bias=True, mlp_ratio=4, embed_dim=D, depth=depth, num_heads=4, patch_size=16).eval()
+    model = vt.VisionTransformer(qkv_bias=True, mlp_ratio=4, embed_dim=D, depth=depth, num_heads=2, patch_size=16).eval()
     model.load_state_dict(sd, strict=True)
     probe = pr.DepthHead(feat_dim=[D] * 4, head_type="linear", kernel_size=1, prediction_type="bindepth")
     probe.load_state_dict(oprobes.make_linear_head_weights([D] * 4, 256, 1, seed=32), strict=True)
