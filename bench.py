@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec through ViT-B/16 multilayer (4 taps, train-mode tap BN)
+feature extraction + linear depth-probe train step (DepthHead linear k=1 bindepth -> bilinear
+upsample -> DepthLoss -> backward -> AdamW -> LambdaLR) on 224x224 synthetic batches.
+
+    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+One "step" = the train_depth.py:99-143 loop body over one per-GPU batch already resident in
+HBM.  Rank 0 prints ONE JSON line (contract in the task statement) carrying, besides the
+throughput, a `roofline` object for the dominant kernel (the split-bf16 MFMA GEMM; algorithmic
+2*M*N*K flops per launch / HIP-event duration on the launch stream) and a `cpu_baseline`
+object (the CPU oracle — a port of the reference path — timed on the host cores on a bounded
+sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "midvision-probe_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (reference default batch_size: 16)")
+    ap.add_argument("--image-size", default="224", help="S or HxW (480x640 = BASELINE config #2)")
+    ap.add_argument("--precision", default=os.environ.get("MVP_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: cgroup quota (the GPU box gives a 16-core share of
+    a 256-core host) > affinity mask > os.cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return int(os.environ.get("MVP_CPU_THREADS", min(n, 16)))
+
+
+def flops_per_image(N: int, D: int = 768, depth: int = 12, head_out: int = 256, taps: int = 4) -> float:
+    """ViT fwd = depth*[N*14,155,776 + 4*N^2*768] + (N-1)*1,179,648; linear head
+    (token resolution, conv1x1 and bilinear commute) fwd + dW = 2 * 2*(N-1)*taps*D*head_out."""
+    vit = depth * (N * (2 * (3 * D * D + D * D + 8 * D * D)) + 4 * N * N * D) + (N - 1) * 2 * D * D
+    head = 2 * 2 * (N - 1) * taps * D * head_out
+    return float(vit + head)
+
+
+def main():
+    args = parse_args()
+    warnings.simplefilter("ignore")
+    from mvp import dist as mdist
+
+    rank, local, world = mdist.env_setup("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if "x" in args.image_size:
+        H, W = (int(v) for v in args.image_size.split("x"))
+    else:
+        H = W = int(args.image_size)
+    B = args.batch
+
+    from evals.models.dino import DINO
+    from evals.models.probes import DepthHead
+    from evals.utils.losses import DepthLoss
+    from evals.utils.optim import cosine_decay_linear_warmup
+    from mvp import backbone as bb
+    from mvp import ops
+    from mvp.optim import FlatAdamW
+    from mvp.train import train_depth_step
+
+    # random-init weights of the ViT-B/16 architecture (no network for checkpoints), same on every rank
+    vsd = bb.random_vit_state_dict(seed=0)
+    model = DINO(return_multilayer=True, add_norm=True, weights=vsd, precision=args.precision).to(dev)
+    torch.manual_seed(0)
+    probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth",
+                      min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+    opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}])
+    total_steps = args.warmup + args.steps + 8
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 10 * total_steps, 1.5 * total_steps))
+    loss_fn = DepthLoss()
+
+    # synthetic NYU-shaped batches, generated per (rank, step), resident in HBM before timing
+    def make_batch(step):
+        g = torch.Generator().manual_seed(1000 * rank + step)
+        images = torch.randn(B, 3, H, W, generator=g)
+        depth = torch.rand(B, 1, H, W, generator=g) * 9.9 + 0.05
+        depth[torch.rand(B, 1, H, W, generator=g) < 0.1] = 0.0
+        return images.to(dev), depth.to(dev)
+
+    n_distinct = 4
+    batches = [make_batch(s) for s in range(n_distinct)]
+
+    def step(i):
+        images, target = batches[i % n_distinct]
+        return train_depth_step(model, probe, opt, sched, loss_fn, images, target)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    loss_acc = torch.zeros((), device=dev)
+    for i in range(args.warmup):
+        loss_acc += step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss_acc += step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    last_loss = float(loss_acc.item()) / max(args.warmup + args.steps, 1)
+    images_per_s = world * B * args.steps / dt
+
+    gh, gw = -(-H // 16), -(-W // 16)
+    N = 1 + gh * gw
+    f_img = flops_per_image(N)
+
+    # ---------------- roofline leg: per-launch HIP-event timing of the dominant kernel (GEMM)
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        trace = []
+        ops.set_trace(trace)
+        nrep = 3
+        for i in range(nrep):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        ops.set_trace(None)
+        groups = {}
+        for kind, tile, prec, flops, e0, e1 in trace:
+            key = (kind, tile)
+            gsum = groups.setdefault(key, [0.0, 0.0, 0])
+            gsum[0] += flops
+            gsum[1] += e0.elapsed_time(e1) * 1e-3
+            gsum[2] += 1
+        # dominant = the kernel instantiation with the largest total time
+        dom = max(groups.items(), key=lambda kv: kv[1][1])
+        (kind, tile), (fl, sec, cnt) = dom
+        achieved = fl / sec / 1e12
+        name = f"gemm_kernel<{tile}>" if kind == "gemm" else "attention_kernel"
+        roofline = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
+            "traffic": None, "kernel": name, "launches_per_step": cnt // nrep, "avg_launch_us": round(sec / cnt * 1e6, 2),
+            "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
+            "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop); HIP events on the launch stream",
+            "all_kernels": {f"{k[0]}:{k[1]}": {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2),
+                                                "alg_tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in groups.items()},
+            "whole_step_alg_tflops": round(images_per_s / world * f_img / 1e12, 2),
+        }
+
+    # ---------------- CPU baseline leg: the oracle (port of the reference CPU path) on the host cores
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import probes as oprobes
+        from oracle import train as otrain
+
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        psd = {"head.conv.weight": probe.head.conv.weight.detach().cpu().clone(), "head.conv.bias": probe.head.conv.bias.detach().cpu().clone()}
+        tr = otrain.DepthProbeTrainer(vsd, psd, max_step=1000, warmup_step=150)
+        Bc = B
+        ci, ct = otrain.synthetic_depth_batch(Bc, H, W, rank=0, step=0)
+        tr.step(ci, ct.clone())  # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        for s in range(args.cpu_steps):
+            ci, ct = otrain.synthetic_depth_batch(Bc, H, W, rank=0, step=1 + s)
+            tr.step(ci, ct)
+        cdt = time.perf_counter() - t0
+        cpu = {"value": round(Bc * args.cpu_steps / cdt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+               "sample": f"{args.cpu_steps} steps of B={Bc} {H}x{W} (same step: extract 4 taps + linear bindepth probe + DepthLoss + backward + AdamW), 1 warm-up step, torch {torch.__version__} CPU fp32"}
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec feature-extract+probe-step, ViT-B/16 224^2" if (H, W) == (224, 224) else f"images/sec feature-extract+probe-step, ViT-B/16 {H}x{W}",
+            "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/LN/softmax/loss)" if args.precision == "bf16x3" else "bf16 (MFMA, fp32 accumulate)",
+            "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",
+            "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(linear,k=1,bindepth) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",
+                       "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
+                       "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
+            "mean_loss": round(last_loss, 5),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -264,9 +264,14 @@ typedef struct {
 int mvp_angular_loss_fwd_bwd(const mvp_angular_loss_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Column sums of a fp32 matrix [M, N] -> out[N] (bias gradients).  out is overwritten.
+ * Column sums of a fp32 matrix [M, N] -> out[N] (bias gradients), deterministic two-level sum.
  * ---------------------------------------------------------------------------------- */
-typedef struct { const float* x; float* out; int M, N, ld; } mvp_colsum_args;
+typedef struct {
+  const float* x; float* out; int M, N, ld;
+  int accumulate;                       /* 1: out += column sums (gradient accumulation) */
+  void* workspace; int64_t workspace_bytes; /* >= mvp_colsum_workspace_bytes(M, N)       */
+} mvp_colsum_args;
+int64_t mvp_colsum_workspace_bytes(int M, int N);
 int mvp_colsum(const mvp_colsum_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------

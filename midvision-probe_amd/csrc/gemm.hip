@@ -3,31 +3,61 @@
 //   Y[M,N] = act(A[M,K] · W[N,K]ᵀ + bias) + residual
 //
 // Both operands are K-contiguous (torch Linear layout), so A and W tiles share one LDS
-// image format: [rows][64 bf16] (128-B rows), filled with 16-byte global_load_lds
-// (LDS-DMA, no VGPR round trip), XOR-swizzled on the SOURCE address (chunk ^= row & 7) so
-// that the ds_read_b128 fragment reads are bank-conflict-free (the LDS destination of an
-// LDS-DMA is lane-linear, hence the swizzle lives on the global side + the read side).
+// image format: [rows][BK bf16], filled with 16-byte global_load_lds (LDS-DMA, no VGPR
+// round trip), XOR-swizzled on the SOURCE address so that the ds_read_b128 fragment reads are
+// bank-conflict-free (the LDS destination of an LDS-DMA is lane-linear, hence the swizzle
+// lives on the global side + the read side):
+//   BK = 64 (128-B rows, 8 chunks):  chunk ^= row & 7
+//   BK = 32 ( 64-B rows, 4 chunks):  chunk ^= {0,2,3,1}[(row >> 2) & 3]
+// BK = 32 halves the LDS footprint, so 2-3 workgroups stay resident per CU (the hot-path
+// GEMMs have only 150-900 tiles: residency, not the MFMA pipe, is the first limiter) and one
+// workgroup's epilogue overlaps another's main loop.
 //
-// The MFMA is issued "swapped": the W fragment is the A operand and the activation
-// fragment the B operand, so each lane's 4 accumulator registers are 4 CONSECUTIVE output
-// columns of one output row -> 16-byte fp32 / 8-byte bf16 epilogue stores, float4 bias and
-// residual loads.
+// The MFMA is issued "swapped": the W fragment is the A operand and the activation fragment
+// the B operand, so each lane's 4 accumulator registers are 4 CONSECUTIVE output columns of
+// one output row.  The epilogue goes through LDS (per-wave private region, reusing the
+// staging buffers): accumulators are written as float4, read back row-contiguous, and stored
+// as whole 128/256-byte row segments (8-byte-per-lane scattered stores measured 1.2 TB/s and
+// cost 36 % of the fc1 GEMM; full-line stores remove that).
 //
-// SPLIT == 3 runs hi*hi + hi*lo + lo*hi (three MFMAs per tile) on bf16 pairs: operand
-// error ~2^-17 instead of 2^-9, which is what the reference's 1e-3 feature parity needs.
+// SPLIT == 3 runs hi*hi + hi*lo + lo*hi (three MFMAs per tile) on bf16 pairs: operand error
+// ~2^-17 instead of 2^-9, which is what the reference's 1e-3 feature parity needs.
 #include "mvp_common.h"
+
+// Diagnostic builds only (tools/gemm_bench.py compiles separate .so files with these set):
+//   MVP_ABLATE 1: no MFMA (fragments read and kept live), 2: no LDS-DMA after the first tile,
+//   3: LDS-DMA + barriers only, 4: epilogue only.  The shipped library is built with 0.
+#ifndef MVP_ABLATE
+#define MVP_ABLATE 0
+#endif
 
 namespace {
 
-template <int BM, int BN, int SPLIT>
+// Branch-free erf GELU: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one
+// v_rcp.  (ocml erff measured ~17 us of VALU on the fc1 epilogue.)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-ax * ax);
+  const float erf_abs = 1.0f - poly * e;
+  const float erfv = copysignf(erf_abs, x);
+  return 0.5f * x * (1.0f + erfv);
+}
+
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
-  constexpr int A_BYTES = BM * 128;
-  constexpr int W_BYTES = BN * 128;
+  constexpr int ROWB = BK * 2;            // bytes per LDS row
+  constexpr int CH = ROWB / 16;           // 16-byte chunks per row (8 or 4)
+  constexpr int RPP = 1024 / ROWB;        // rows per 1-KiB LDS-DMA piece (8 or 16)
+  constexpr int A_BYTES = BM * ROWB;
+  constexpr int W_BYTES = BN * ROWB;
   constexpr int STAGE = (A_BYTES + W_BYTES) * NARR;
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave output tile (2x2 waves)
   constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int KS = BK / 32;              // MFMA k-steps per tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -35,32 +65,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int nk = p.K >> 6;
+#if MVP_ABLATE == 4
+  const int nk = 0;
+#else
+  const int nk = p.K / BK;
+#endif
 
-  const int rsub = lane >> 3;                 // row inside an 8-row LDS-DMA piece
-  const int csrc = ((lane & 7) ^ rsub) << 3;  // swizzled source chunk, in elements
+  const int rsub = lane / CH;  // row inside an LDS-DMA piece
+  const int csw = (BK == 64) ? (rsub & 7) : ((0x1320 >> (((rsub >> 2) & 3) * 4)) & 3);
+  const int csrc = (((lane % CH) ^ csw)) << 3;  // swizzled source chunk, in elements
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
-    const int k0 = kt << 6;
+    const int k0 = kt * BK;
 #pragma unroll
-    for (int ps = 0; ps < BM / 32; ++ps) {
-      const int r = ps * 32 + wave * 8;
+    for (int ps = 0; ps < BM / (4 * RPP); ++ps) {
+      const int r = ps * 4 * RPP + wave * RPP;
       const int grow = min(m0 + r + rsub, p.M - 1);
       const size_t off = (size_t)grow * p.lda + k0 + csrc;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_hi + off), LDS_PTR(base + r * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_hi + off), LDS_PTR(base + r * ROWB), 16, 0, 0);
       if (SPLIT == 3)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_lo + off), LDS_PTR(base + A_BYTES + r * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_lo + off), LDS_PTR(base + A_BYTES + r * ROWB), 16, 0, 0);
     }
     char* wb = base + A_BYTES * NARR;
 #pragma unroll
-    for (int ps = 0; ps < BN / 32; ++ps) {
-      const int r = ps * 32 + wave * 8;
+    for (int ps = 0; ps < BN / (4 * RPP); ++ps) {
+      const int r = ps * 4 * RPP + wave * RPP;
       const int grow = min(n0 + r + rsub, p.N - 1);
       const size_t off = (size_t)grow * p.ldw + k0 + csrc;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_hi + off), LDS_PTR(wb + r * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_hi + off), LDS_PTR(wb + r * ROWB), 16, 0, 0);
       if (SPLIT == 3)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_lo + off), LDS_PTR(wb + W_BYTES + r * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_lo + off), LDS_PTR(wb + W_BYTES + r * ROWB), 16, 0, 0);
     }
   };
 
@@ -70,35 +105,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets: row = tile row + (lane & 15), chunk = ks*4 + (lane >> 4), XOR (row & 7)
+  // fragment reads: row = tile row + (lane & 15), chunk = ks*4 + (lane >> 4), XOR swizzle(row)
   const int frow = lane & 15;
   const int fq = lane >> 4;
-  const int fx = lane & 7;
+  const int fsw = (BK == 64) ? (lane & 7) : ((0x1320 >> ((((lane & 15) >> 2) & 3) * 4)) & 3);
 
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // Software pipeline: NSTAGE LDS buffers, NSTAGE-1 tiles of LDS-DMA in flight.  Per iteration:
+  // counted vmcnt (this wave's pieces of tile kt have landed; younger tiles stay in flight) ->
+  // raw s_barrier (everybody's pieces landed AND everybody finished reading tile kt-1, whose
+  // buffer is the one restaged next) -> issue tile kt+NSTAGE-1 -> MFMAs on tile kt.
+  // __syncthreads() is NOT used in the loop: its fence would drain the in-flight LDS-DMA.
+  constexpr int LOADS = (BM / (4 * RPP) + BN / (4 * RPP)) * NARR;  // LDS-DMA instructions per wave per tile
+#pragma unroll
+  for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+    if (s0 < nk) stage(s0, s0);
 
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* base = smem + (kt & 1) * STAGE;
-    const char* ab = base + (wm0 + frow) * 128;
-    const char* wb = base + A_BYTES * NARR + (wn0 + frow) * 128;
+    if (kt + NSTAGE - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#if MVP_ABLATE != 2
+    if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+#endif
+#if MVP_ABLATE == 3
+    continue;
+#endif
+    const char* base = smem + (kt % NSTAGE) * STAGE;
+    const char* ab = base + (wm0 + frow) * ROWB;
+    const char* wb = base + A_BYTES * NARR + (wn0 + frow) * ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int coff = (((ks << 2) + fq) ^ fx) << 4;
+    for (int ks = 0; ks < KS; ++ks) {
+      const int coff = (((ks << 2) + fq) ^ fsw) << 4;
       bf16x8_t a_hi[MT], w_hi[NT];
       bf16x8_t a_lo[MT], w_lo[NT];
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
-        a_hi[j] = *(const bf16x8_t*)(ab + j * 16 * 128 + coff);
-        if (SPLIT == 3) a_lo[j] = *(const bf16x8_t*)(ab + A_BYTES + j * 16 * 128 + coff);
+        a_hi[j] = *(const bf16x8_t*)(ab + j * 16 * ROWB + coff);
+        if (SPLIT == 3) a_lo[j] = *(const bf16x8_t*)(ab + A_BYTES + j * 16 * ROWB + coff);
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        w_hi[i] = *(const bf16x8_t*)(wb + i * 16 * 128 + coff);
-        if (SPLIT == 3) w_lo[i] = *(const bf16x8_t*)(wb + W_BYTES + i * 16 * 128 + coff);
+        w_hi[i] = *(const bf16x8_t*)(wb + i * 16 * ROWB + coff);
+        if (SPLIT == 3) w_lo[i] = *(const bf16x8_t*)(wb + W_BYTES + i * 16 * ROWB + coff);
       }
+#if MVP_ABLATE == 1
+#pragma unroll
+      for (int j = 0; j < MT; ++j) { asm volatile("" ::"v"(a_hi[j])); if (SPLIT == 3) asm volatile("" ::"v"(a_lo[j])); }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) { asm volatile("" ::"v"(w_hi[i])); if (SPLIT == 3) asm volatile("" ::"v"(w_lo[i])); }
+      continue;
+#endif
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -110,73 +170,87 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_hi[j], acc[i][j], 0, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // every wave is done with the staging buffers -> reuse them for the epilogue
+
+  // ---------------------------------------------------------------- epilogue through LDS
+  // Per-wave private scratch [32 rows][WN + 4] fp32; the trailing barrier of the main loop has
+  // retired every read of the staging buffers, so they can be reused.
+  constexpr int EPW = WN + 4;                 // padded row, floats (conflict-free b128 write/read)
+  constexpr int EP_BYTES = 32 * EPW * 4;      // per wave
+  constexpr int LPR = WN / 4;                 // lanes per output row (16 or 8)
+  constexpr int RPI = 64 / LPR;               // rows per wave-instruction (4 or 8)
+  float* ep = (float*)(smem + wave * EP_BYTES);
+  const int er = lane / LPR, ec = (lane % LPR) * 4;
+  const int ncol = n0 + wn0 + ec;
+  const bool vec_ok = ((p.N & 3) == 0) && (ncol + 3 < p.N);
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ncol + e < p.N) bias4[e] = p.bias[ncol + e];
   }
 
-  // ---- epilogue: lane owns row m (= lane & 15 of each m-tile) and 4 consecutive columns
-  const bool vec_ok = ((p.N & 3) == 0);
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const int m = m0 + wm0 + j * 16 + frow;
-    if (m >= p.M) continue;
-    int orow = m;
-    if (p.row_group > 0) {
-      const int gidx = m / p.row_group;
-      orow = gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
-    }
-    const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : orow;
+  for (int h = 0; h < MT / 2; ++h) {
+    // phase 1: accumulators -> LDS (lane: row frow of m-tile, cols i*16 + 4*fq ..)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int n = n0 + wn0 + i * 16 + fq * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const bool full = vec_ok && (n + 3 < p.N);
-      if (p.bias) {
-        if (full) {
-          const float4 b = *(const float4*)(p.bias + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        } else {
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += p.bias[n + e];
-        }
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        *(f32x4_t*)(ep + (jj * 16 + frow) * EPW + i * 16 + fq * 4) = acc[i][h * 2 + jj];
+    // phase 2: row-contiguous read-back, fused bias / activation / residual, full-line stores
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int lr = it * RPI + er;
+      const int m = m0 + wm0 + h * 32 + lr;
+      const f32x4_t a4 = *(const f32x4_t*)(ep + lr * EPW + ec);
+      if (m >= p.M || ncol >= p.N) continue;
+      int orow = m;
+      if (p.row_group > 0) {
+        const int gidx = m / p.row_group;
+        orow = gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
       }
+      const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : orow;
+      float v[4] = {a4[0] + bias4[0], a4[1] + bias4[1], a4[2] + bias4[2], a4[3] + bias4[3]};
       if (p.act == MVP_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
       } else if (p.act == MVP_ACT_RELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (p.residual) {
-        const float* rp = p.residual + (size_t)rrow * p.ldr + n;
-        if (full && ((p.ldr & 3) == 0)) {
+        const float* rp = p.residual + (size_t)rrow * p.ldr + ncol;
+        if (vec_ok && ((p.ldr & 3) == 0)) {
           const float4 r = *(const float4*)rp;
           v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
         } else {
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += rp[e];
+          for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
         }
       }
       if (p.out_f32) {
-        float* op = p.out_f32 + (size_t)orow * p.ldo + n;
-        if (full && ((p.ldo & 3) == 0)) {
+        float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
+        if (vec_ok && ((p.ldo & 3) == 0)) {
           *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          for (int e = 0; e < 4; ++e) if (n + e < p.N) op[e] = v[e];
+          for (int e = 0; e < 4; ++e) if (ncol + e < p.N) op[e] = v[e];
         }
       }
       if (p.out_hi) {
-        uint16_t h[4], l[4];
+        uint16_t hh[4], ll[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split_bf16(v[e], h[e], l[e]);
-        const size_t o = (size_t)orow * p.ldob + n;
-        if (full && ((p.ldob & 3) == 0)) {
-          *(u32x2_t*)(p.out_hi + o) = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
-          if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+        for (int e = 0; e < 4; ++e) split_bf16(v[e], hh[e], ll[e]);
+        const size_t o = (size_t)orow * p.ldob + ncol;
+        if (vec_ok && ((p.ldob & 3) == 0)) {
+          *(u32x2_t*)(p.out_hi + o) = u32x2_t{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
+          if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{pack2(ll[0], ll[1]), pack2(ll[2], ll[3])};
         } else {
           for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) {
-              p.out_hi[o + e] = h[e];
-              if (p.out_lo) p.out_lo[o + e] = l[e];
+            if (ncol + e < p.N) {
+              p.out_hi[o + e] = hh[e];
+              if (p.out_lo) p.out_lo[o + e] = ll[e];
             }
         }
       }
@@ -184,23 +258,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   }
 }
 
-template <int BM, int BN, int SPLIT>
-int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
+constexpr int gemm_smem() {
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
-  constexpr int SMEM = 2 * (BM + BN) * 128 * NARR;
+  constexpr int stages = NSTAGE * (BM + BN) * BK * 2 * NARR;
+  constexpr int epi = 4 * 32 * (BN / 2 + 4) * 4;
+  return stages > epi ? stages : epi;
+}
+
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
+int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
+  constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE>();
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
   static int configured = [] {
-    return (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, SPLIT>,
+    return (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, SPLIT>), dim3(tiles), dim3(256), SMEM, s, *a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE>), dim3(tiles), dim3(256), SMEM, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
 
 }  // namespace
 
+// Diagnostic override (tools/gemm_bench.py): -DMVP_F_BM=.. -DMVP_F_BN=.. -DMVP_F_BK=.. -DMVP_F_ST=..
 extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (!a || !a->a_hi || !a->w_hi) return MVP_EINVAL;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & 63)) return MVP_EINVAL;
@@ -210,10 +293,21 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = a->precision == MVP_PREC_BF16X3;
-  // Tile choice: the hot-path GEMMs have M = B*N tokens (~3k at B=16, 224^2) so the grid,
-  // not the MFMA pipe, is the first limiter: use 128x128 only when that still gives >= 2
-  // waves of workgroups over the 256 CUs, otherwise the 128x64 tile (2x the blocks).
+#ifdef MVP_F_BM
+  return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST>(a, s) : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST>(a, s);
+#else
+  // Tile choice (measured on MI355X at the hot-path shapes, tools/gemm_bench.py; M = B*N ~ 3k rows):
+  // the grid, not the MFMA pipe, is the first limiter, and resident workgroups per CU matter
+  // more than pipeline depth (a third stage that costs residency loses), so: 2 stages, BK = 32
+  // for the split mode (48-64 KB LDS -> 2-3 workgroups/CU), 128x128 only when that still gives
+  // >= ~1.5 waves of tiles, long-K skinny-N (the probe head) on BK = 64.
   const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
-  if (t128 >= 512) return x3 ? launch_gemm<128, 128, 3>(a, s) : launch_gemm<128, 128, 1>(a, s);
-  return x3 ? launch_gemm<128, 64, 3>(a, s) : launch_gemm<128, 64, 1>(a, s);
+  if (x3) {
+    if (t128 >= 400) return launch_gemm<128, 128, 32, 3, 2>(a, s);
+    if (a->N <= 256 && a->K >= 2048) return launch_gemm<128, 64, 64, 3, 2>(a, s);
+    return launch_gemm<128, 64, 32, 3, 2>(a, s);
+  }
+  if (t128 >= 400) return launch_gemm<128, 128, 64, 1, 2>(a, s);
+  return launch_gemm<128, 64, 64, 1, 2>(a, s);
+#endif
 }

@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int DL_NCH = 32;   // chunks per image in the statistics pass
-constexpr int DL_NCH2 = 64;  // chunks in the pair pass
+constexpr int DL_NCH2 = 512; // chunks in the pair pass
 constexpr int DL_SCAL = 16;  // fp64 scalars
 
 __device__ __forceinline__ double block_sum(double v, double* red) {

@@ -66,17 +66,30 @@ __global__ __launch_bounds__(256) void depth_sigmoid_bwd(const mvp_depth_predict
   }
 }
 
-// Column sums: block = 64 columns x 4 row groups, fixed reduction order (deterministic).
-__global__ __launch_bounds__(256) void colsum_kernel(const mvp_colsum_args p) {
+// Column sums, deterministic two-level reduction: level 1 = (64-column strip) x (row chunk)
+// workgroups write partial sums into the workspace, level 2 adds the chunks in a fixed order.
+constexpr int CS_CHUNK = 64;  // rows per level-1 workgroup
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const mvp_colsum_args p, float* part) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * CS_CHUNK, r1 = min(p.M, r0 + CS_CHUNK);
   float s = 0.f;
   if (c < p.N)
-    for (int r = rg; r < p.M; r += 4) s += p.x[(size_t)r * p.ld + c];
+    for (int r = r0 + rg; r < r1; r += 4) s += p.x[(size_t)r * p.ld + c];
   red[rg][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rg == 0 && c < p.N) p.out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rg == 0 && c < p.N)
+    part[(size_t)blockIdx.y * p.N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const mvp_colsum_args p, const float* part, int nchunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= p.N) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * p.N + c];
+  p.out[c] = p.accumulate ? p.out[c] + s : s;
 }
 
 inline int grid_for(int64_t work) {
@@ -114,9 +127,17 @@ extern "C" int mvp_depth_predict_bwd(const mvp_depth_predict_args* a, void* stre
   return MVP_OK;
 }
 
+extern "C" int64_t mvp_colsum_workspace_bytes(int M, int N) {
+  return (int64_t)((M + CS_CHUNK - 1) / CS_CHUNK) * N * 4;
+}
+
 extern "C" int mvp_colsum(const mvp_colsum_args* a, void* stream) {
-  if (!a || !a->x || !a->out || a->M <= 0 || a->N <= 0 || a->ld < a->N) return MVP_EINVAL;
-  hipLaunchKernelGGL(colsum_kernel, dim3((a->N + 63) / 64), dim3(256), 0, (hipStream_t)stream, *a);
+  if (!a || !a->x || !a->out || !a->workspace || a->M <= 0 || a->N <= 0 || a->ld < a->N) return MVP_EINVAL;
+  if (a->workspace_bytes < mvp_colsum_workspace_bytes(a->M, a->N)) return MVP_EINVAL;
+  const int nchunk = (a->M + CS_CHUNK - 1) / CS_CHUNK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((a->N + 63) / 64, nchunk), dim3(256), 0, s, *a, (float*)a->workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((a->N + 255) / 256), dim3(256), 0, s, *a, (const float*)a->workspace, nchunk);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

@@ -89,6 +89,16 @@ __global__ __launch_bounds__(256) void resize_fwd_planar(const mvp_resize_args p
   }
 }
 
+// Adjoint weight of output index o on input index i along one axis (0 when o does not touch i).
+__device__ __forceinline__ float adj_w(int mode, int align, float scale, int o, int in, int i) {
+  const Taps t = taps_1d(mode, align, scale, o, in);
+  float w = 0.f;
+  for (int a = 0; a < t.n; ++a) w += (t.idx[a] == i) ? t.w[a] : 0.f;
+  return w;
+}
+
+constexpr int ADJ_MAXW = 24;  // candidate columns whose weights are cached in registers
+
 __global__ __launch_bounds__(256) void resize_bwd_planar(const mvp_resize_args p) {
   const float sh = src_scale(p.Hi, p.Ho, p.align_corners, p.scale_h);
   const float sw = src_scale(p.Wi, p.Wo, p.align_corners, p.scale_w);
@@ -102,18 +112,25 @@ __global__ __launch_bounds__(256) void resize_bwd_planar(const mvp_resize_args p
     cand_range(p.mode, p.align_corners, sh, iy, p.Hi, p.Ho, ylo, yhi);
     cand_range(p.mode, p.align_corners, sw, ix, p.Wi, p.Wo, xlo, xhi);
     const float* g = p.src + pl * p.Ho * p.Wo;
+    const int nx = xhi - xlo + 1;
+    float wxs[ADJ_MAXW];
+    const bool cached = nx <= ADJ_MAXW;
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < ADJ_MAXW; ++k) wxs[k] = (k < nx) ? adj_w(p.mode, p.align_corners, sw, xlo + k, p.Wi, ix) : 0.f;
+    }
     float acc = 0.f;
     for (int oy = ylo; oy <= yhi; ++oy) {
-      const Taps ty = taps_1d(p.mode, p.align_corners, sh, oy, p.Hi);
-      float wy = 0.f;
-      for (int a = 0; a < ty.n; ++a) wy += (ty.idx[a] == iy) ? ty.w[a] : 0.f;
+      const float wy = adj_w(p.mode, p.align_corners, sh, oy, p.Hi, iy);
       if (wy == 0.f) continue;
+      const float* grow = g + (size_t)oy * p.Wo + xlo;
       float rowacc = 0.f;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const Taps tx = taps_1d(p.mode, p.align_corners, sw, ox, p.Wi);
-        float wx = 0.f;
-        for (int b = 0; b < tx.n; ++b) wx += (tx.idx[b] == ix) ? tx.w[b] : 0.f;
-        if (wx != 0.f) rowacc += wx * g[(size_t)oy * p.Wo + ox];
+      if (cached) {
+#pragma unroll
+        for (int k = 0; k < ADJ_MAXW; ++k)
+          if (k < nx) rowacc += wxs[k] * grow[k];
+      } else {
+        for (int k = 0; k < nx; ++k) rowacc += adj_w(p.mode, p.align_corners, sw, xlo + k, p.Wi, ix) * grow[k];
       }
       acc += wy * rowacc;
     }
@@ -162,20 +179,34 @@ __global__ __launch_bounds__(256) void resize_bwd_cl(const mvp_resize_args p) {
     cand_range(p.mode, p.align_corners, sh, iy, p.Hi, p.Ho, ylo, yhi);
     cand_range(p.mode, p.align_corners, sw, ix, p.Wi, p.Wo, xlo, xhi);
     const float4* g = (const float4*)p.src + b * p.Ho * p.Wo * C4 + c;
+    const int nx = xhi - xlo + 1;
+    float wxs[ADJ_MAXW];
+    const bool cached = nx <= ADJ_MAXW;
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < ADJ_MAXW; ++k) wxs[k] = (k < nx) ? adj_w(p.mode, p.align_corners, sw, xlo + k, p.Wi, ix) : 0.f;
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int oy = ylo; oy <= yhi; ++oy) {
-      const Taps ty = taps_1d(p.mode, p.align_corners, sh, oy, p.Hi);
-      float wy = 0.f;
-      for (int a = 0; a < ty.n; ++a) wy += (ty.idx[a] == iy) ? ty.w[a] : 0.f;
+      const float wy = adj_w(p.mode, p.align_corners, sh, oy, p.Hi, iy);
       if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const Taps tx = taps_1d(p.mode, p.align_corners, sw, ox, p.Wi);
-        float wx = 0.f;
-        for (int q = 0; q < tx.n; ++q) wx += (tx.idx[q] == ix) ? tx.w[q] : 0.f;
-        if (wx == 0.f) continue;
-        const float w = wy * wx;
-        const float4 v = g[((size_t)oy * p.Wo + ox) * C4];
-        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+      const float4* grow = g + ((size_t)oy * p.Wo + xlo) * C4;
+      if (cached) {
+#pragma unroll
+        for (int k = 0; k < ADJ_MAXW; ++k) {
+          if (k < nx && wxs[k] != 0.f) {
+            const float w = wy * wxs[k];
+            const float4 v = grow[(size_t)k * C4];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+          }
+        }
+      } else {
+        for (int k = 0; k < nx; ++k) {
+          const float w = wy * adj_w(p.mode, p.align_corners, sw, xlo + k, p.Wi, ix);
+          if (w == 0.f) continue;
+          const float4 v = grow[(size_t)k * C4];
+          acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
       }
     }
     ((float4*)p.dst)[i] = acc;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const mvp_cls_rows_args p
 }
 
 // ----------------------------------------------------------------------------- BN over tokens
-constexpr int BN_RB = 32;  // rows per partial-statistics slab
+constexpr int BN_RB = 8;   // rows per partial-statistics slab (small slabs -> ~400 workgroups at M ~ 3k)
 
 // Pass 1: per 32-row slab and channel, shifted sums (shift = first row of the slab) so that
 // the later variance is free of catastrophic cancellation even when |mean| >> std.
@@ -96,14 +96,24 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Pass 2: Chan's pairwise combination of the slabs in fp64 -> mean, biased var; running
-// stats (momentum, unbiased var) and the affine scale/shift used by the apply pass.
+// Pass 2: one wave per channel.  Each lane folds its slabs (stride 64) with Chan's update in
+// fp64, then the 64 lane-partials are combined by an xor-shuffle tree (fixed order ->
+// deterministic) -> mean, biased var; running stats (momentum, unbiased var) and the affine
+// scale/shift used by the apply pass.
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m, 64);
+  hi = __shfl_xor(hi, m, 64);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
                                                           float* __restrict__ ss, int M, int nslab) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= p.C) return;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int s = 0; s < nslab; ++s) {
+  for (int s = lane; s < nslab; s += 64) {
     const float* o = part + ((size_t)s * p.C + c) * 3;
     const double nb = (double)min(BN_RB, M - s * BN_RB);
     const double mb = (double)o[0] + (double)o[1] / nb;
@@ -114,6 +124,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const mvp_bn_tokens_ar
     m2 += m2b + delta * delta * n * nb / nn;
     n = nn;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double n2 = shfl_xor_f64(n, o), mean2 = shfl_xor_f64(mean, o), m22 = shfl_xor_f64(m2, o);
+    const double nn = n + n2;
+    if (nn > 0.0) {
+      const double delta = mean2 - mean;
+      // symmetric form so that both partners compute the identical combined triple
+      const double cm = (n * mean + n2 * mean2) / nn;
+      m2 = m2 + m22 + delta * delta * n * n2 / nn;
+      mean = cm;
+    }
+    n = nn;
+  }
+  if (lane != 0) return;
   const double var = m2 / n;
   p.stats[c] = (float)mean;
   p.stats[p.C + c] = (float)var;
@@ -281,7 +305,7 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   float* ss = part + (size_t)nslab * a->C * 3;
   if (a->mode == 0) {
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, a->x, part, M, a->C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, part, ss, M, nslab);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 3) / 4), dim3(256), 0, s, *a, part, ss, M, nslab);
   } else {
     hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
   }

@@ -99,7 +99,7 @@ class AngularLossArgs(C.Structure):
 
 
 class ColsumArgs(C.Structure):
-    _fields_ = [("x", _vp), ("out", _vp), ("M", _i), ("N", _i), ("ld", _i)]
+    _fields_ = [("x", _vp), ("out", _vp), ("M", _i), ("N", _i), ("ld", _i), ("accumulate", _i), ("workspace", _vp), ("workspace_bytes", _i64)]
 
 
 class AdamWArgs(C.Structure):
@@ -132,6 +132,7 @@ SYMBOLS = {
     "mvp_depth_loss_workspace_bytes": None,
     "mvp_depth_loss_fwd_bwd": DepthLossArgs,
     "mvp_angular_loss_fwd_bwd": AngularLossArgs,
+    "mvp_colsum_workspace_bytes": None,
     "mvp_colsum": ColsumArgs,
     "mvp_adamw_step": AdamWArgs,
     "mvp_corr_argmax": CorrArgmaxArgs,
@@ -162,6 +163,8 @@ def load() -> C.CDLL:
     lib.mvp_strerror.restype = C.c_char_p
     lib.mvp_bn_tokens_workspace_bytes.argtypes = [_i, _i]
     lib.mvp_bn_tokens_workspace_bytes.restype = _i64
+    lib.mvp_colsum_workspace_bytes.argtypes = [_i, _i]
+    lib.mvp_colsum_workspace_bytes.restype = _i64
     lib.mvp_depth_loss_workspace_bytes.argtypes = [_i, _i64]
     lib.mvp_depth_loss_workspace_bytes.restype = _i64
     _lib = lib

@@ -15,6 +15,27 @@ from .lib import PREC_BF16, PREC_BF16X3
 
 Pair = Tuple[torch.Tensor, Optional[torch.Tensor]]
 
+# Optional per-launch timing hook used by bench.py's roofline leg: when a list is installed,
+# every GEMM / attention launch is bracketed by HIP events recorded on the launch stream.
+_TRACE = None
+
+
+def set_trace(lst) -> None:
+    global _TRACE
+    _TRACE = lst
+
+
+def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3) -> str:
+    """Mirror of the tile choice in csrc/gemm.hip -> template arguments BM,BN,BK,SPLIT,NSTAGE."""
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if precision == PREC_BF16X3:
+        if t128 >= 400:
+            return "128, 128, 32, 3, 2"
+        if N <= 256 and K >= 2048:
+            return "128, 64, 64, 3, 2"
+        return "128, 64, 32, 3, 2"
+    return "128, 128, 64, 1, 2" if t128 >= 400 else "128, 64, 64, 1, 2"
+
 
 def _chk(t: torch.Tensor, dtype, name: str):
     if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
@@ -60,7 +81,14 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
         lda if lda is not None else K, ldw if ldw is not None else K,
         ldr if ldr is not None else N, ldo if ldo is not None else N, ldob if ldob is not None else N,
         act, precision, row_group, row_group_stride, row_group_off, res_row_mod)
+    if _TRACE is None:
+        lib.call("mvp_gemm_bias_act_res", args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     lib.call("mvp_gemm_bias_act_res", args)
+    e1.record()
+    _TRACE.append(("gemm", gemm_tile(M, N, K, precision), precision, 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,
@@ -72,7 +100,14 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pai
 def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None) -> None:
     a = lib.AttentionArgs(lib.ptr(qkv[0]), lib.ptr(qkv[1]), lib.ptr(out[0]), lib.ptr(out[1]), B, N, H,
                           ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision)
+    if _TRACE is None:
+        lib.call("mvp_attention_fwd", a)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     lib.call("mvp_attention_fwd", a)
+    e1.record()
+    _TRACE.append(("attention", "4x32q", precision, 4.0 * B * H * N * N * 64, e0, e1))
 
 
 def cls_rows(cls: torch.Tensor, pos0: torch.Tensor, x: torch.Tensor, B: int, N: int, Cdim: int) -> None:
@@ -135,8 +170,11 @@ def angular_loss(pred, gt, mask_u8, loss, grad_pred, workspace, B, Cp, HW, eps=1
     lib.call("mvp_angular_loss_fwd_bwd", a)
 
 
-def colsum(x, out, M, N, ld=None) -> None:
-    lib.call("mvp_colsum", lib.ColsumArgs(lib.ptr(x), lib.ptr(out), M, N, ld if ld is not None else N))
+def colsum(x, out, M, N, ld=None, accumulate=False, workspace=None) -> None:
+    if workspace is None:
+        workspace = torch.empty(int(lib.load().mvp_colsum_workspace_bytes(M, N)) // 4 + 4, dtype=torch.float32, device=x.device)
+    lib.call("mvp_colsum", lib.ColsumArgs(lib.ptr(x), lib.ptr(out), M, N, ld if ld is not None else N, int(accumulate),
+                                          lib.ptr(workspace), workspace.numel() * workspace.element_size()))
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0) -> None:

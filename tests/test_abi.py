@@ -46,7 +46,8 @@ def test_bad_arguments_return_einval():
     assert so.mvp_attention_fwd(ctypes.byref(b), None) == -1  # ld_qkv < 3*H*64
     c = lib.LayerNormArgs(x=16, gamma=16, beta=16, out_hi=16, M=1, C=4098)
     assert so.mvp_layernorm_fwd(ctypes.byref(c), None) == -1
-    assert so.mvp_bn_tokens_workspace_bytes(3152, 768) == (99 * 768 * 3 + 2 * 768) * 4
+    assert so.mvp_bn_tokens_workspace_bytes(3152, 768) == (394 * 768 * 3 + 2 * 768) * 4  # 8-row slabs
+    assert so.mvp_colsum_workspace_bytes(3136, 256) == 49 * 256 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""GEMM microbenchmark + ablation (diagnostic).  Builds ablated copies of gemm.hip into
+gpurun_out/ and times the hot-path shapes with HIP events, interleaved rounds in one process."""
+import ctypes as C, os, subprocess, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "midvision-probe_amd"))
+import torch
+from mvp import lib, ops
+
+CS = os.path.join(REPO, "midvision-probe_amd", "csrc")
+OUT = os.path.join(REPO, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+
+def build(ablate, extra=""):
+    so = os.path.join(OUT, f"libgemm_ab{ablate}{extra.replace(' ','').replace('-D','_').replace('=','')}.so")
+    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ABLATE={ablate} {extra} {CS}/gemm.hip -o {so}"
+    subprocess.run(cmd, shell=True, check=True)
+    l = C.CDLL(so)
+    l.mvp_gemm_bias_act_res.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
+    l.mvp_gemm_bias_act_res.restype = C.c_int
+    return l
+
+def main():
+    variants = {"auto": build(0)}
+    def cfg(bm, bn, bk, st):
+        return build(0, f"-DMVP_F_BM={bm} -DMVP_F_BN={bn} -DMVP_F_BK={bk} -DMVP_F_ST={st}")
+    if "--tiles" in sys.argv:
+        for c in ((128,128,64,2),(128,128,32,2),(128,128,32,3),(128,128,32,4),(128,64,64,2),(128,64,32,2),(128,64,32,3),(128,64,32,4),(128,64,64,3)):
+            try:
+                variants["%dx%dk%ds%d" % c] = cfg(*c)
+            except Exception as e:
+                print("build failed", c)
+    if "--ablate" in sys.argv:
+        variants.update({"no_load": build(2), "load_only": build(3), "epi_only": build(4)})
+    dev = torch.device("cuda")
+    B = int(os.environ.get("B", 16)); M = B * 197
+    shapes = [("qkv", M, 2304, 768), ("proj", M, 768, 768), ("fc1", M, 3072, 768), ("fc2", M, 768, 3072), ("head", B * 196, 256, 3072)]
+    for prec in (3, 1):
+        for name, m, n, k in shapes:
+            a = ops.split_bf16(torch.randn(m, k, device=dev), 3); w = ops.split_bf16(torch.randn(n, k, device=dev) * 0.05, 3)
+            out = ops.empty_pair((m, n), 3, dev); o32 = torch.empty(m, n, device=dev); bias = torch.randn(n, device=dev)
+            args = lib.GemmArgs(a[0].data_ptr(), a[1].data_ptr(), w[0].data_ptr(), w[1].data_ptr(), bias.data_ptr(), None,
+                                None, out[0].data_ptr(), out[1].data_ptr(), m, n, k, k, k, n, n, n, 0, prec, 0, 0, 0, 0)
+            st = torch.cuda.current_stream().cuda_stream
+            res = {}
+            for rnd in range(3):
+                for vn, l in variants.items():
+                    for _ in range(3): l.mvp_gemm_bias_act_res(C.byref(args), st)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(20): l.mvp_gemm_bias_act_res(C.byref(args), st)
+                    e1.record(); torch.cuda.synchronize()
+                    res.setdefault(vn, []).append(e0.elapsed_time(e1) / 20 * 1e3)
+            fl = 2.0 * m * n * k
+            line = f"prec={prec} {name:5s} M={m} N={n} K={k}: " + "  ".join(f"{vn}={min(v):6.1f}us({fl/min(v)/1e6:4.0f})" for vn, v in res.items())
+            print(line, flush=True)
+
+if __name__ == "__main__":
+    main()
