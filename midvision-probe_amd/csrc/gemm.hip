@@ -304,10 +304,10 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
   if (x3) {
     if (t128 >= 400) return launch_gemm<128, 128, 32, 3, 2>(a, s);
-    if (a->N <= 256 && a->K >= 2048) return launch_gemm<128, 64, 64, 3, 2>(a, s);
+    if (a->N <= 256 && a->K >= 2048) return launch_gemm<64, 64, 64, 3, 2>(a, s);
     return launch_gemm<128, 64, 32, 3, 2>(a, s);
   }
   if (t128 >= 400) return launch_gemm<128, 128, 64, 1, 2>(a, s);
-  return launch_gemm<128, 64, 64, 1, 2>(a, s);
+  return launch_gemm<64, 64, 64, 1, 2>(a, s);
 #endif
 }

@@ -107,6 +107,7 @@ class _LinearHeadK1(torch.autograd.Function):
         ops.resize(l0, lq, B, h, w, 4 * h, 4 * w, lib.RESIZE_BILINEAR, channels_last=True, Cdim=K4, scale_h=4.0, scale_w=4.0)
         ctx.pack, ctx.precision, ctx.K, ctx.K4 = pack, precision, K, K4
         ctx.wshape = weight.shape
+        ctx.generation = pack.generation
         return lq
 
     @staticmethod
@@ -114,11 +115,16 @@ class _LinearHeadK1(torch.autograd.Function):
         pack, pr, K, K4 = ctx.pack, ctx.precision, ctx.K, ctx.K4
         B, h, w, Ctot = pack.B, pack.h, pack.w, pack.Ctot
         dev = glq.device
+        if pack.generation != ctx.generation:
+            raise lib.MvpError("linear head backward: the backbone ran again before this backward and overwrote the packed "
+                               "features of this step (call backward before the next model(images))")
         glq = glq.contiguous()
         gl0 = torch.empty(pack.M, K4, dtype=torch.float32, device=dev)
         ops.resize(glq, gl0, B, h, w, 4 * h, 4 * w, lib.RESIZE_BILINEAR, channels_last=True, Cdim=K4, scale_h=4.0, scale_w=4.0, backward=True)
         # dW[K, Ctot] = gl0ᵀ · F : both operands K-major over the (zero padded) token axis
-        gT = ops.zeros_pair((K4, pack.Mpad), pr, dev)
+        gT = pack.scratch.get(("gT", K4))
+        if gT is None:  # pad columns [M, Mpad) are zeroed once and never written
+            gT = pack.scratch[("gT", K4)] = ops.zeros_pair((K4, pack.Mpad), pr, dev)
         ops.pack_nchw_tokens(gl0, 1, pack.M, K4, tok=gT, ld_tok=pack.Mpad, col_off=0)
         dW = torch.empty(K4, Ctot, dtype=torch.float32, device=dev)
         ops.gemm(gT, pack.tokT, K4, Ctot, pack.Mpad, out_f32=dW, precision=pr)

@@ -32,9 +32,9 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3) -> str:
         if t128 >= 400:
             return "128, 128, 32, 3, 2"
         if N <= 256 and K >= 2048:
-            return "128, 64, 64, 3, 2"
+            return "64, 64, 64, 3, 2"
         return "128, 64, 32, 3, 2"
-    return "128, 128, 64, 1, 2" if t128 >= 400 else "128, 64, 64, 1, 2"
+    return "128, 128, 64, 1, 2" if t128 >= 400 else "64, 64, 64, 1, 2"
 
 
 def _chk(t: torch.Tensor, dtype, name: str):

@@ -52,6 +52,8 @@ class PackedFeatures:
         self.tok = ops.zeros_pair((self.Mpad, self.Cpad), precision, device)
         self.tokT = ops.zeros_pair((Ctot, self.Mpad), precision, device)
         self.sources: List[Tuple[int, int]] = []  # (data_ptr, _version) of the NCHW maps packed here
+        self.generation = 0  # bumped every time the buffers are rewritten (they are reused across steps)
+        self.scratch: Dict[str, object] = {}  # per-shape scratch of the head backward (zero-padded once)
 
 
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
@@ -111,6 +113,7 @@ class ViTEngine:
         self.hidden = self.blocks[0]["fc1_b"].numel()
         self._ws: Dict[Tuple[int, int, int], dict] = {}
         self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._packs: Dict[Tuple[int, int, int, int], PackedFeatures] = {}
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, B: int, gh: int, gw: int) -> dict:
@@ -202,7 +205,14 @@ class ViTEngine:
         N, C, hw = 1 + gh * gw, self.C, gh * gw
         layers = list(layers)
         outs = TapOutputs()
-        packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device) if pack else None
+        packed = None
+        if pack:  # reuse the (zero padded) packing buffers across steps: only the valid region is rewritten
+            pkey = (B, gh, gw, len(layers))
+            packed = self._packs.get(pkey)
+            if packed is None:
+                packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device)
+                self._packs = {pkey: packed}
+            packed.generation += 1
         stats = torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device)
 
         def tap(j):
