@@ -33,6 +33,28 @@ def env_setup(backend: str = "nccl"):
     return rank, local, world
 
 
+def all_reduce_sum_flat(flat: torch.Tensor, group=None) -> int:
+    """The ONE data-path collective of a training step: SUM over ranks of the flat fp32 probe
+    gradient (RCCL over xGMI on GPUs, gloo in the CPU tests).  Returns the world size; the caller
+    folds 1/world into the optimiser kernel.  No-op (returns 1) when not distributed."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return dist.get_world_size(group)
+    return 1
+
+
+def flat_layout(shapes):
+    """Offsets of each parameter inside the flat buffer (every view 16-byte aligned)."""
+    offs, off = [], 0
+    for shp in shapes:
+        n = 1
+        for d in shp:
+            n *= int(d)
+        offs.append((off, n))
+        off += (n + 3) // 4 * 4
+    return offs, off
+
+
 def shard_indices(n: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):
     """DistributedSampler semantics (builder.py:50-51, train_depth.py:94-95): permutation seeded
     by seed+epoch, padded by wrap-around to a multiple of world, rank r takes r, r+W, ..."""

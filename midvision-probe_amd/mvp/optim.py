@@ -74,12 +74,9 @@ class FlatAdamW(torch.optim.Optimizer):
     def all_reduce_grads(self):
         """One collective per step: SUM over ranks of the flat fp32 gradient (RCCL over xGMI);
         the 1/world average is folded into the AdamW kernel's grad_scale."""
-        import torch.distributed as dist
+        from .dist import all_reduce_sum_flat
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.process_group)
-            return dist.get_world_size(self.process_group)
-        return 1
+        return all_reduce_sum_flat(self.flat_grad, self.process_group)
 
     @torch.no_grad()
     def step(self, closure=None):
