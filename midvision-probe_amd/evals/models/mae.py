@@ -43,7 +43,7 @@ class MAE(bb.ViTBackbone):
         self._setup_taps(self.vit.embed_dim, layer, return_multilayer, add_norm, self.vit.depth)
         self.batchnorms = nn.ModuleList([nn.BatchNorm1d(self.vit.embed_dim) for _ in self.multilayers])
         self.return_kqv, self.fixed_size, self.mode_selected = return_kqv, fixed_size, mode_selected
-        self.heads, self.ln_eps, self.pos_embed_mode = 12, 1e-12, "fixed"
+        self.heads, self.ln_eps, self.pos_embed_mode = self.vit.embed_dim // 64, 1e-12, "fixed"
         self.set_precision(precision or bb.default_precision())
 
     def resize_pos_embed(self, image_size):

@@ -36,10 +36,10 @@ class MoCoV3(bb.ViTBackbone):
         self.output = output
         self.checkpoint_name = f"$mocov3$_{arch}_{output}"
         self.patch_size = self.model.patch_embed.proj.weight.shape[-1]
-        self._setup_taps(768, -1, return_multilayer, add_norm, self.model.depth)
-        self.batchnorms = nn.ModuleList([nn.BatchNorm1d(768) for _ in self.multilayers])
+        self._setup_taps(self.model.embed_dim, -1, return_multilayer, add_norm, self.model.depth)  # 768 for the real ViT-B/16
+        self.batchnorms = nn.ModuleList([nn.BatchNorm1d(self.model.embed_dim) for _ in self.multilayers])
         self.return_kqv, self.fixed_size, self.mode_selected = return_kqv, fixed_size, mode_selected
-        self.heads, self.ln_eps, self.pos_embed_mode = 12, 1e-6, "fixed"
+        self.heads, self.ln_eps, self.pos_embed_mode = self.model.embed_dim // 64, 1e-6, "fixed"
         self.set_precision(precision or bb.default_precision())
 
     def forward(self, images):

@@ -1,0 +1,62 @@
+"""SPair-71k keypoint-correspondence hot path (evaluate_spair_correspondence.py:45-103).
+
+``correspondence`` runs the fused HIP kernel (L2-normalise over C, bilinear keypoint sampling,
+cosine heat-map, 2-D argmax); ``compute_errors`` mirrors the reference function's signature and
+return values (the PCK bookkeeping on K<=~30 keypoints is host-side glue)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import lib, ops
+
+
+def correspondence(feats_i: torch.Tensor, feats_j: torch.Tensor, kps_i_xy01: torch.Tensor):
+    """feats_* [C,h,w] fp32 device maps (un-normalised), kps_i_xy01 [K,2] in [0,1] (x,y).
+    Returns (pred_xy [K,2] int64 (col,row), max_val [K]) on the device."""
+    if not feats_i.is_cuda:
+        raise lib.MvpError("spair.correspondence needs device tensors (no CPU fallback)")
+    C, h, w = feats_i.shape
+    K = kps_i_xy01.shape[0]
+    dev = feats_i.device
+    ndc = (kps_i_xy01.to(dev, torch.float32) * 2 - 1).contiguous()
+    out_xy = torch.empty(K, 2, dtype=torch.int64, device=dev)
+    out_val = torch.empty(K, dtype=torch.float32, device=dev)
+    ws = torch.empty(2 * h * w + K * C + 16, dtype=torch.float32, device=dev)
+    ops.corr_argmax(feats_i.contiguous().float(), feats_j.contiguous().float(), ndc, out_xy, out_val, ws, C, h, w, K)
+    return out_xy, out_val
+
+
+def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
+    """Reference: evaluate_spair_correspondence.py:45-103.  ``instance`` =
+    (img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _)."""
+    if mask_feats or return_heatmaps:
+        raise NotImplementedError("mask_feats / return_heatmaps are outside the hot path (heat-maps are never materialised)")
+    img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _ = instance
+    dev = torch.device("cuda", torch.cuda.current_device())
+    images = torch.stack((img_i, img_j)).to(dev)
+    feats = model(images)  # NB: the reference runs this outside no_grad with the wrapper in train mode
+    if isinstance(feats, list):
+        feats = torch.cat(feats, dim=1)
+    assert images.shape[-1] == images.shape[-2], "assuming square images here"
+    kps_i = kps_i.float().clone()
+    kps_j = kps_j.float().clone()
+    kps_i[:, :2] = kps_i[:, :2] / images.shape[-1]
+    kps_j[:, :2] = kps_j[:, :2] / images.shape[-1]
+    pred_xy, _ = correspondence(feats[0], feats[1], kps_i[:, :2])
+    pred_kp = pred_xy.float().cpu() / feats.shape[-1]
+    errors = (pred_kp[:, None, :] - kps_j[None, :, :2]).norm(p=2, dim=-1)
+    errors = errors / thresh_scale
+    valid_kps = (kps_i[:, None, 2] * kps_j[None, :, 2]) == 1
+    in_both = valid_kps.diagonal()
+    errors[valid_kps.logical_not()] = 1e3
+    error_same = errors.diagonal()[in_both]
+    error_nn, index_nn = errors[in_both].min(dim=1)
+    index_same = in_both.nonzero().squeeze(1)
+    return error_same, error_nn, index_same, index_nn
+
+
+def shard_pairs(n_pairs: int, rank: int, world: int):
+    """Image pairs are independent (tap BN couples only the two images of a pair): rank r takes
+    pairs r, r+W, ...; per-pair error vectors are gathered at the end."""
+    return list(range(rank, n_pairs, world))

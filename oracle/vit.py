@@ -107,13 +107,37 @@ def interpolate_pos_encoding(pos_embed: torch.Tensor, npatch: int, w: int, h: in
     return torch.cat((cls_pos.unsqueeze(0), grid), dim=1)
 
 
-def prepare_tokens(sd: StateDict, images: torch.Tensor, patch: int = 16) -> torch.Tensor:
-    """ibot_transformers.py:338-355 — conv16/16 patch embed, prepend CLS, add pos-embed."""
+def prepare_tokens(sd: StateDict, images: torch.Tensor, patch: int = 16, pos_mode: str = "dino") -> torch.Tensor:
+    """ibot_transformers.py:338-355 — conv16/16 patch embed, prepend CLS, add pos-embed.
+    pos_mode "fixed": the stored table is added as is (timm ViT in mocov3.py:154-157; HF ViT-MAE
+    embed_forward, mae.py:91-104 — there CLS gets cls_token + pos[0], which is the same sum)."""
     B, _, d2, d3 = images.shape
     x = F.conv2d(images, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=patch)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat((sd["cls_token"].expand(B, -1, -1), x), dim=1)
+    if pos_mode == "fixed":
+        return x + sd["pos_embed"]
     return x + interpolate_pos_encoding(sd["pos_embed"], x.shape[1] - 1, d2, d3, patch)
+
+
+def sincos_pos_embed_2d(embed_dim: int, grid_hw, add_cls_token: bool = True) -> torch.Tensor:
+    """evals/models/utils.py:75-102 (+ the HF helper it calls): 2-D sin/cos table, the first
+    half of the channels encodes the w coordinate, the second half h; each half = [sin | cos] of
+    pos / 10000^(2i/(D/2)); a zero row is prepended for CLS."""
+    import numpy as np
+
+    gh, gw = grid_hw
+    ww, hh = np.meshgrid(np.arange(gw, dtype=np.float32), np.arange(gh, dtype=np.float32))
+
+    def enc(pos, d):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=float) / (d / 2.0))
+        ang = pos.reshape(-1)[:, None] * omega[None, :]
+        return np.concatenate([np.sin(ang), np.cos(ang)], axis=1)
+
+    emb = np.concatenate([enc(ww, embed_dim // 2), enc(hh, embed_dim // 2)], axis=1)
+    if add_cls_token:
+        emb = np.concatenate([np.zeros([1, embed_dim]), emb], axis=0)
+    return torch.from_numpy(emb).float().unsqueeze(0)
 
 
 def attention(sd: StateDict, prefix: str, x: torch.Tensor, heads: int) -> torch.Tensor:
@@ -207,17 +231,39 @@ def vit_dense_features(
     bn_training: bool = True,
     ln_eps: float = 1e-6,
     return_tokens: bool = False,
+    pos_mode: str = "dino",
+    tap_input_of_block: bool = False,
+    resize_to=None,
 ):
     """DINO.forward, dino.py:164-210 (``return_kqv`` False): pad -> tokens -> blocks with
     taps after the listed block indices (tap = optional train-mode BatchNorm1d over tokens)
     -> drop CLS -> NCHW.  The final ``vit.norm`` is never applied."""
+    if resize_to is not None:  # MoCoV3.forward, mocov3.py:150-152
+        images = F.interpolate(images, size=tuple(resize_to), mode="bilinear", align_corners=False)
     images = center_padding(images, patch)
     h, w = images.shape[-2] // patch, images.shape[-1] // patch
     depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
-    x = prepare_tokens(sd, images, patch)
+    x = prepare_tokens(sd, images, patch, pos_mode)
     layers = list(layers)
     taps = []
+
+    def tap_now(j, x):
+        if add_norm:
+            wgt, b = bn_affine[j] if bn_affine is not None else (None, None)
+            run = bn_running[j] if bn_running is not None else None
+            taps.append(batchnorm_tokens_train(x, wgt, b, run, training=bn_training))
+        else:
+            taps.append(x)
+
     for i in range(depth):
+        if tap_input_of_block:
+            # MAE.forward taps HF ``hidden_states[i]`` = the INPUT of encoder layer i (mae.py:216-217, quirk Q4)
+            if i in layers:
+                tap_now(layers.index(i), x)
+                if len(taps) == len(layers):
+                    break
+            x = block(sd, i, x, heads, ln_eps)
+            continue
         x = block(sd, i, x, heads, ln_eps)
         if i in layers:
             j = layers.index(i)
