@@ -107,6 +107,19 @@ typedef struct {
   int act;                /* MVP_ACT_*                                          */
   int precision;          /* MVP_PREC_*                                         */
   int row_group, row_group_stride, row_group_off, res_row_mod;
+  /* --- implicit-GEMM convolution (conv != 0): A = channels-last activation [B, cH>>cup, cW>>cup, cC]
+   * read as the im2col of its (nearest-upsampled by 2^cup) [B, cH, cW, cC] view; K = ckh*ckw*cC with
+   * k = (ky*ckw + kx)*cC + c (weights laid out [N, ckh, ckw, cC]); M = B*cHo*cWo; cC % 32 == 0.
+   * Replaces nn.Conv2d 3x3 / strided convs of probes.py:283-306,318-375 and the ResNet trunk
+   * (dino_res50.py:38-51); padding taps read the caller's zero page (>= 256 zero bytes).           */
+  int conv, cH, cW, cC, cHo, cWo, ckh, ckw, cstride, cpad, cup;
+  const mvp_bf16* zero_page;
+  /* --- ReLU bookkeeping (byte masks, row stride ldm):
+   * out_mask  (forward): 1 where the activated value (before any residual add) is > 0;
+   * relu_mask (backward): gate by a saved mask; mask_mode 2 gates the result before the residual
+   * add, mask_mode 1 gates only the bf16-pair output (out_f32 stays un-gated: skip-path gradient). */
+  const uint8_t* relu_mask; uint8_t* out_mask; int ldm; int mask_mode;
+  const float* residual2; /* optional second fp32 addend, same row stride ldr (fusion-block "+ skip") */
 } mvp_gemm_args;
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
 
@@ -302,6 +315,59 @@ typedef struct {
   int C, h, w, K;
 } mvp_corr_argmax_args;
 int mvp_corr_argmax(const mvp_corr_argmax_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution weight re-layout (per step; the probe's conv weights are trained):
+ *   mode 0: [Cout,Cin,kh,kw] fp32 -> forward GEMM operand [Cout, kh*kw*Cin] bf16 pair (k = tap*Cin + c)
+ *   mode 1: -> data-gradient operand [Cin, kh*kw*Cout] (k = tap'*Cout + n, taps flipped)
+ * Replaces the implicit weight access of nn.Conv2d fwd / bwd-data (probes.py:283-288,371-375).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* w; mvp_bf16* out_hi; mvp_bf16* out_lo;
+  int Cout, Cin, kh, kw, mode;
+} mvp_conv_weight_pack_args;
+int mvp_conv_weight_pack(const mvp_conv_weight_pack_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Nearest-neighbour upsample by an integer factor f on channels-last fp32 [B,H,W,C]
+ * (F.interpolate(x, scale_factor=f), probes.py:388,396,398); backward = f x f block sums
+ * (src is then the fine [B,H*f,W*f,C] gradient).  Outputs: fp32 and/or bf16 pair.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src; float* dst_f32; mvp_bf16* dst_hi; mvp_bf16* dst_lo;
+  int B, H, W, C, f; int backward; /* H,W = COARSE dims in both directions */
+} mvp_upsample_cl_args;
+int mvp_upsample_nearest_cl(const mvp_upsample_cl_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution weight gradient (TN GEMM over pixels, split-K):
+ *   dW[n, c, ky, kx] (+)= sum_m G[m, n] * X[pix(m, ky, kx), c]
+ * G = output gradient [M = B*Ho*Wo, ldg] channels-last bf16 pair (ldg >= roundup(Cout,128),
+ * pad columns zero), X = layer input [B, H>>up, W>>up, ldx] channels-last bf16 pair seen through
+ * a nearest upsample by 2^up; Cin % 128 == 0.  1x1 convs / linear layers use kh=kw=1, pad=0.
+ * partial: fp32 workspace of mvp_gemm_tn_workspace_bytes(...) bytes.  Replaces the autograd
+ * weight-gradient of nn.Conv2d (probes.py:283-288,352-355,371-375).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const mvp_bf16* g_hi; const mvp_bf16* g_lo; const mvp_bf16* x_hi; const mvp_bf16* x_lo;
+  float* partial; float* dw; const mvp_bf16* zero_page; /* >= 512 zero bytes */
+  int64_t M; int Cout, Cin, ldg, ldx;
+  int H, W, Ho, Wo, kh, kw, stride, pad, up;
+  int splits, accumulate, precision;
+} mvp_gemm_tn_args;
+/* ------------------------------------------------------------------------------------
+ * Gradient gate + split: dst = src * (mask != 0) as fp32 (may alias src) and as a bf16 pair
+ * with row stride ldo >= N (pad columns zeroed) — the ReLU backward of probes.py:283-288 fused
+ * with the operand conversion for the next MFMA GEMM.  mask may be NULL (plain split).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src; const uint8_t* mask; float* dst_f32; mvp_bf16* dst_hi; mvp_bf16* dst_lo;
+  int64_t M; int N, lds, ldm, ldo;
+} mvp_mask_split_args;
+int mvp_mask_split(const mvp_mask_split_args*, void* stream);
+
+int64_t mvp_gemm_tn_workspace_bytes(int Cout, int Cin, int kh, int kw, int splits);
+int mvp_gemm_tn_conv(const mvp_gemm_tn_args*, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,306 @@
+// Convolution support kernels for the DPT / ResNet path (channels-last bf16 pairs):
+//   conv_weight_pack   torch [Cout, Cin, kh, kw] fp32 -> GEMM operand [rows, K] bf16 pair
+//                      mode 0 (forward):        rows = Cout, k = (t)*Cin + c
+//                      mode 1 (data gradient):  rows = Cin,  k = (t')*Cout + n with t' the flipped tap
+//   upsample_nearest_cl fwd / bwd (integer factor) on [B, H, W, C] fp32 (+ bf16 pair copy)
+//   gemm_tn_conv       weight gradient  dW[i, (t, c)] = sum_m G[m, i] * X[pix(m, t), c]
+//                      both operands are pixel-major (K = pixels), staged by LDS-DMA and consumed
+//                      through ds_read_b64_tr_b16; split-K over pixel ranges into fp32 partial slabs
+//   splitk_reduce      sum of the slabs (fixed order) -> torch-layout gradient (optionally +=)
+#include "mvp_common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- weight pack
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const mvp_conv_weight_pack_args p) {
+  const int T = p.kh * p.kw;
+  const int64_t total = (int64_t)p.Cout * p.Cin * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // destination-major indexing so that writes are coalesced
+    float v;
+    if (p.mode == 0) {
+      const int c = (int)(i % p.Cin);
+      const int64_t r = i / p.Cin;
+      const int t = (int)(r % T), n = (int)(r / T);
+      v = p.w[((int64_t)n * p.Cin + c) * T + t];
+    } else {
+      const int n = (int)(i % p.Cout);
+      const int64_t r = i / p.Cout;
+      const int t = (int)(r % T), c = (int)(r / T);
+      v = p.w[((int64_t)n * p.Cin + c) * T + (T - 1 - t)];
+    }
+    uint16_t h, l;
+    split_bf16(v, h, l);
+    p.out_hi[i] = h;
+    if (p.out_lo) p.out_lo[i] = l;
+  }
+}
+
+// ----------------------------------------------------------------------------- nearest upsample (channels-last)
+__global__ __launch_bounds__(256) void upsample_nearest_cl_fwd(const mvp_upsample_cl_args p) {
+  const int C4 = p.C >> 2, Ho = p.H * p.f, Wo = p.W * p.f;
+  const int64_t total = (int64_t)p.B * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int x = (int)(r % Wo); r /= Wo;
+    const int y = (int)(r % Ho);
+    const int64_t b = r / Ho;
+    const float4 v = ((const float4*)p.src)[((b * p.H + y / p.f) * p.W + x / p.f) * C4 + c];
+    if (p.dst_f32) ((float4*)p.dst_f32)[i] = v;
+    if (p.dst_hi) {
+      uint16_t h[4], l[4];
+      split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]); split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+      ((u32x2_t*)p.dst_hi)[i] = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
+      if (p.dst_lo) ((u32x2_t*)p.dst_lo)[i] = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+    }
+  }
+}
+
+// adjoint: dst[b, y, x, c] = sum over the f x f block of src (src is the fine grid)
+__global__ __launch_bounds__(256) void upsample_nearest_cl_bwd(const mvp_upsample_cl_args p) {
+  const int C4 = p.C >> 2, Wo = p.W * p.f, Ho = p.H * p.f;
+  const int64_t total = (int64_t)p.B * p.H * p.W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int x = (int)(r % p.W); r /= p.W;
+    const int y = (int)(r % p.H);
+    const int64_t b = r / p.H;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < p.f; ++dy)
+      for (int dx = 0; dx < p.f; ++dx) {
+        const float4 v = ((const float4*)p.src)[((b * Ho + y * p.f + dy) * Wo + x * p.f + dx) * C4 + c];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    if (p.dst_f32) ((float4*)p.dst_f32)[i] = a;
+    if (p.dst_hi) {
+      uint16_t h[4], l[4];
+      split_bf16(a.x, h[0], l[0]); split_bf16(a.y, h[1], l[1]); split_bf16(a.z, h[2], l[2]); split_bf16(a.w, h[3], l[3]);
+      ((u32x2_t*)p.dst_hi)[i] = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
+      if (p.dst_lo) ((u32x2_t*)p.dst_lo)[i] = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- TN weight-gradient GEMM
+// Tile: 128 output channels (i) x 128 input channels (j) of ONE tap; K-tile = 32 pixels.
+// LDS images [32 pixel rows][128 channels] (256-B rows), 16-B chunk c of row r stored at
+// chunk c ^ (f(r) << 1), f(r) = (r & 3) | ((r >> 1) & 4): the 8 rows a half-wave touches in one
+// ds_read_b64_tr_b16 (rows 8g..8g+3 of two lane groups) land on 8 distinct 32-B bank slots.
+// MFMA roles: A operand = X fragment (rows = input channel j), B operand = G fragment
+// (cols = output channel i): each lane then owns 4 consecutive j of one i -> 16-byte stores
+// into dW's [i][tap][j] rows.
+template <int SPLIT>
+__global__ __launch_bounds__(256) void gemm_tn_conv_kernel(const mvp_gemm_tn_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NARR = (SPLIT == 3) ? 2 : 1;
+  constexpr int TILE = 32 * 256;             // one [32][128] bf16 image
+  constexpr int STAGE = 2 * NARR * TILE;     // G (hi[,lo]) then X (hi[,lo])
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g4 = lane >> 4, c16 = lane & 15;
+
+  const int T = p.kh * p.kw;
+  const int jt_per_tap = p.Cin / 128;
+  const int tiles_j = T * jt_per_tap;
+  const int tiles_i = (p.Cout + 127) / 128;
+  int bid = blockIdx.x;
+  const int split = bid / (tiles_i * tiles_j);
+  bid -= split * tiles_i * tiles_j;
+  const int ti = bid / tiles_j, tj = bid - ti * tiles_j;
+  const int tap = tj / jt_per_tap, c0 = (tj - tap * jt_per_tap) * 128, i0 = ti * 128;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  // pixel range of this split (multiple of 32)
+  const int64_t per = ((p.M + p.splits - 1) / p.splits + 31) / 32 * 32;
+  const int64_t mbeg = (int64_t)split * per, mend = min<int64_t>(p.M, mbeg + per);
+  const int nk = (mend > mbeg) ? (int)((mend - mbeg + 31) / 32) : 0;
+  const int Hs = p.H >> p.up, Ws = p.W >> p.up;
+
+  // staging: a piece = 4 rows x 256 B; wave w stages rows w*8 .. w*8+7 (two pieces)
+  const int rsub = lane >> 4;                      // row inside a piece (0..3)
+  auto fsw = [](int r) { return (r & 3) | ((r >> 1) & 4); };
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int r = wave * 8 + ps * 4 + rsub;      // tile row (pixel)
+      const int64_t m = mbeg + (int64_t)kt * 32 + r;
+      const int cs = (c16 ^ (fsw(r) << 1)) << 3;   // swizzled source chunk (elements)
+      const bool inr = m < mend;
+      // G row
+      const size_t goff = (size_t)(inr ? m : 0) * p.ldg + i0 + cs;
+      const mvp_bf16* gh = inr ? p.g_hi + goff : p.zero_page + cs;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gh), LDS_PTR(base + (wave * 8 + ps * 4) * 256), 16, 0, 0);
+      if (SPLIT == 3) {
+        const mvp_bf16* gl = inr ? p.g_lo + goff : p.zero_page + cs;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(gl), LDS_PTR(base + TILE + (wave * 8 + ps * 4) * 256), 16, 0, 0);
+      }
+      // X row of the tap's source pixel
+      bool ok = inr;
+      size_t xoff = 0;
+      if (inr) {
+        const int x = (int)(m % p.Wo);
+        const int64_t t2 = m / p.Wo;
+        const int y = (int)(t2 % p.Ho);
+        const int64_t b = t2 / p.Ho;
+        const int yy = y * p.stride + ky - p.pad, xx = x * p.stride + kx - p.pad;
+        ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
+        xoff = ((size_t)(b * Hs + (yy >> p.up)) * Ws + (xx >> p.up)) * p.ldx + c0 + cs;
+      }
+      const mvp_bf16* xh = ok ? p.x_hi + xoff : p.zero_page + cs;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xh), LDS_PTR(base + NARR * TILE + (wave * 8 + ps * 4) * 256), 16, 0, 0);
+      if (SPLIT == 3) {
+        const mvp_bf16* xl = ok ? p.x_lo + xoff : p.zero_page + cs;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xl), LDS_PTR(base + 3 * TILE + (wave * 8 + ps * 4) * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  // wave tile 64 (j) x 64 (i): wave>>1 picks the j half, wave&1 the i half
+  const int wj0 = (wave >> 1) * 64, wi0 = (wave & 1) * 64;
+  f32x4_t acc[4][4];  // [jt][it]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addressing: group g4 supplies rows 8*g4 + q (+4 for the second read), 8-B slot pp
+  const int q = c16 >> 2, pp = lane & 3;
+  auto tr_addr = [&](int row, int col0) {  // col0 multiple of 16 (elements): 32-B chunk index = col0/16
+    const int c32 = col0 >> 4;
+    return row * 256 + ((c32 ^ fsw(row)) << 5) + ((pp >> 1) << 4) + ((pp & 1) << 3);
+  };
+
+  if (nk > 0) stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* gb = smem + (kt & 1) * STAGE;
+    const char* xb = gb + NARR * TILE;
+    const int r0 = g4 * 8 + q;
+    bf16x8_t xf_hi[4], xf_lo[4], gf_hi[4], gf_lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      {
+        const int a0 = tr_addr(r0, wj0 + t * 16), a1 = tr_addr(r0 + 4, wj0 + t * 16);
+        const bf16x4_t u0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(xb + a0));
+        const bf16x4_t u1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(xb + a1));
+        xf_hi[t] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (SPLIT == 3) {
+          const bf16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(xb + TILE + a0));
+          const bf16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(xb + TILE + a1));
+          xf_lo[t] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+      {
+        const int a0 = tr_addr(r0, wi0 + t * 16), a1 = tr_addr(r0 + 4, wi0 + t * 16);
+        const bf16x4_t u0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(gb + a0));
+        const bf16x4_t u1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(gb + a1));
+        gf_hi[t] = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (SPLIT == 3) {
+          const bf16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(gb + TILE + a0));
+          const bf16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(gb + TILE + a1));
+          gf_lo[t] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (SPLIT == 3) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf_lo[a], gf_hi[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf_hi[a], gf_lo[b], acc[a][b], 0, 0, 0);
+        }
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf_hi[a], gf_hi[b], acc[a][b], 0, 0, 0);
+      }
+  }
+
+  // partial slab [split][Cout][T*Cin]: lane owns i = col (lane & 15), 4 consecutive j (rows 4*g4 ..)
+  float* slab = p.partial + (size_t)split * p.Cout * T * p.Cin;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int i = i0 + wi0 + b * 16 + c16;
+    if (i >= p.Cout) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int j = c0 + wj0 + a * 16 + g4 * 4;
+      *(float4*)(slab + ((size_t)i * T + tap) * p.Cin + j) = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+    }
+  }
+}
+
+// slabs [splits][Cout][T][Cin] -> torch layout [Cout][Cin][T] (+= when accumulate)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const mvp_gemm_tn_args p) {
+  const int T = p.kh * p.kw;
+  const int64_t total = (int64_t)p.Cout * p.Cin * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // source-major (coalesced reads): i = (n*T + t)*Cin + c
+    const int c = (int)(i % p.Cin);
+    const int64_t r = i / p.Cin;
+    const int t = (int)(r % T), n = (int)(r / T);
+    float s = 0.f;
+    for (int k = 0; k < p.splits; ++k) s += p.partial[(size_t)k * total + i];
+    float* d = p.dw + ((int64_t)n * p.Cin + c) * T + t;
+    *d = p.accumulate ? *d + s : s;
+  }
+}
+
+inline int grid_for(int64_t work, int cap = 4096) {
+  int64_t g = (work + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+template <int SPLIT>
+int launch_tn(const mvp_gemm_tn_args* a, hipStream_t s) {
+  constexpr int SMEM = 2 * 2 * ((SPLIT == 3) ? 2 : 1) * 32 * 256;
+  static int configured = [] {
+    return (int)hipFuncSetAttribute((const void*)gemm_tn_conv_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  }();
+  if (configured != 0) return MVP_ELAUNCH;
+  const int T = a->kh * a->kw;
+  const int blocks = a->splits * ((a->Cout + 127) / 128) * T * (a->Cin / 128);
+  hipLaunchKernelGGL((gemm_tn_conv_kernel<SPLIT>), dim3(blocks), dim3(256), SMEM, s, *a);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((int64_t)a->Cout * a->Cin * T)), dim3(256), 0, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+}  // namespace
+
+extern "C" int mvp_conv_weight_pack(const mvp_conv_weight_pack_args* a, void* stream) {
+  if (!a || !a->w || !a->out_hi || a->Cout <= 0 || a->Cin <= 0 || a->kh <= 0 || a->kw <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(grid_for((int64_t)a->Cout * a->Cin * a->kh * a->kw)), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_upsample_nearest_cl(const mvp_upsample_cl_args* a, void* stream) {
+  if (!a || !a->src || (!a->dst_f32 && !a->dst_hi) || a->B <= 0 || a->H <= 0 || a->W <= 0 || a->C <= 0 || (a->C & 3) || a->f < 1) return MVP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (a->backward)
+    hipLaunchKernelGGL(upsample_nearest_cl_bwd, dim3(grid_for((int64_t)a->B * a->H * a->W * (a->C >> 2), 8192)), dim3(256), 0, s, *a);
+  else
+    hipLaunchKernelGGL(upsample_nearest_cl_fwd, dim3(grid_for((int64_t)a->B * a->H * a->W * a->f * a->f * (a->C >> 2), 8192)), dim3(256), 0, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int64_t mvp_gemm_tn_workspace_bytes(int Cout, int Cin, int kh, int kw, int splits) {
+  return (int64_t)splits * Cout * Cin * kh * kw * 4;
+}
+
+extern "C" int mvp_gemm_tn_conv(const mvp_gemm_tn_args* a, void* stream) {
+  if (!a || !a->g_hi || !a->x_hi || !a->partial || !a->dw || !a->zero_page) return MVP_EINVAL;
+  if (a->Cout <= 0 || a->Cin <= 0 || (a->Cin & 127) || a->M <= 0 || a->splits < 1) return MVP_EINVAL;
+  if (a->kh <= 0 || a->kw <= 0 || a->stride <= 0 || a->Ho <= 0 || a->Wo <= 0 || (a->M % ((int64_t)a->Ho * a->Wo))) return MVP_EINVAL;
+  if ((a->ldg & 7) || (a->ldx & 7) || a->ldx < a->Cin || a->ldg < ((a->Cout + 127) / 128) * 128) return MVP_EINVAL;
+  if (a->precision == MVP_PREC_BF16X3) {
+    if (!a->g_lo || !a->x_lo) return MVP_EINVAL;
+    return launch_tn<3>(a, (hipStream_t)stream);
+  }
+  if (a->precision != MVP_PREC_BF16) return MVP_EINVAL;
+  return launch_tn<1>(a, (hipStream_t)stream);
+}

@@ -45,7 +45,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
+// CONV: the A operand is an implicit im2col of a channels-last activation [B, H, W, C]
+// (optionally a virtual nearest-upsample by 2^cup of the stored tensor): K index =
+// (ky*kw + kx)*C + c, output row m = (b, y, x) on the Ho x Wo grid.  A K-tile never straddles
+// a tap (C % BK == 0), so per tile every staged row is ONE 16-byte-aligned run of channels of
+// one source pixel — or of the caller's zero page when the tap falls into the padding.
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV>
 __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
@@ -75,17 +80,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   const int csw = (BK == 64) ? (rsub & 7) : ((0x1320 >> (((rsub >> 2) & 3) * 4)) & 3);
   const int csrc = (((lane % CH) ^ csw)) << 3;  // swizzled source chunk, in elements
 
+  constexpr int APASS = BM / (4 * RPP);
+  int cvb[APASS], cvy[APASS], cvx[APASS];  // conv: image index and top-left input coords of this lane's rows
+  int ct_ky = 0, ct_kx = 0, ct_c0 = 0;     // conv: (tap, channel) position of the next tile to stage
+  if (CONV) {
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+      const int m = min(m0 + ps * 4 * RPP + wave * RPP + rsub, p.M - 1);
+      const int x = m % p.cWo, t = m / p.cWo;
+      cvb[ps] = t / p.cHo;
+      cvy[ps] = (t % p.cHo) * p.cstride - p.cpad;
+      cvx[ps] = x * p.cstride - p.cpad;
+    }
+  }
+  const int cHs = CONV ? (p.cH >> p.cup) : 0, cWs = CONV ? (p.cW >> p.cup) : 0;
+
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
     const int k0 = kt * BK;
 #pragma unroll
-    for (int ps = 0; ps < BM / (4 * RPP); ++ps) {
+    for (int ps = 0; ps < APASS; ++ps) {
       const int r = ps * 4 * RPP + wave * RPP;
-      const int grow = min(m0 + r + rsub, p.M - 1);
-      const size_t off = (size_t)grow * p.lda + k0 + csrc;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_hi + off), LDS_PTR(base + r * ROWB), 16, 0, 0);
-      if (SPLIT == 3)
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_lo + off), LDS_PTR(base + A_BYTES + r * ROWB), 16, 0, 0);
+      if (CONV) {
+        const int yy = cvy[ps] + ct_ky, xx = cvx[ps] + ct_kx;
+        const bool ok = ((unsigned)yy < (unsigned)p.cH) && ((unsigned)xx < (unsigned)p.cW);
+        const size_t off = (((size_t)cvb[ps] * cHs + (yy >> p.cup)) * cWs + (xx >> p.cup)) * p.lda + ct_c0 + csrc;
+        const mvp_bf16* sh = ok ? p.a_hi + off : p.zero_page + csrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(sh), LDS_PTR(base + r * ROWB), 16, 0, 0);
+        if (SPLIT == 3) {
+          const mvp_bf16* sl = ok ? p.a_lo + off : p.zero_page + csrc;
+          __builtin_amdgcn_global_load_lds(GLB_PTR(sl), LDS_PTR(base + A_BYTES + r * ROWB), 16, 0, 0);
+        }
+      } else {
+        const int grow = min(m0 + r + rsub, p.M - 1);
+        const size_t off = (size_t)grow * p.lda + k0 + csrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_hi + off), LDS_PTR(base + r * ROWB), 16, 0, 0);
+        if (SPLIT == 3)
+          __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_lo + off), LDS_PTR(base + A_BYTES + r * ROWB), 16, 0, 0);
+      }
+    }
+    if (CONV) {  // tiles are staged in increasing kt order: advance the running tap position
+      ct_c0 += BK;
+      if (ct_c0 >= p.cC) {
+        ct_c0 = 0;
+        if (++ct_kx == p.ckw) { ct_kx = 0; ++ct_ky; }
+      }
     }
     char* wb = base + A_BYTES * NARR;
 #pragma unroll
@@ -221,6 +260,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
+      if (p.out_mask) {  // forward: remember which outputs the activation kept (ReLU backward gate)
+        uint8_t* mo = p.out_mask + (size_t)orow * p.ldm + ncol;
+        if (vec_ok && ((p.ldm & 3) == 0)) {
+          *(uint32_t*)mo = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 0x100u : 0u) | (v[2] > 0.f ? 0x10000u : 0u) | (v[3] > 0.f ? 0x1000000u : 0u);
+        } else {
+          for (int e = 0; e < 4; ++e) if (ncol + e < p.N) mo[e] = v[e] > 0.f ? 1 : 0;
+        }
+      }
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.relu_mask) {  // backward of ReLU: gate by the saved byte mask
+        const uint8_t* mp = p.relu_mask + (size_t)orow * p.ldm + ncol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] = (ncol + e < p.N && mp[e]) ? 1.f : 0.f;
+        if (p.mask_mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= keep[e];
+        }
+      }
       if (p.residual) {
         const float* rp = p.residual + (size_t)rrow * p.ldr + ncol;
         if (vec_ok && ((p.ldr & 3) == 0)) {
@@ -229,6 +286,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
         } else {
           for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
         }
+      }
+      if (p.residual2) {
+        const float* rp = p.residual2 + (size_t)orow * p.ldr + ncol;
+        for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
       }
       if (p.out_f32) {
         float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
@@ -241,7 +302,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       if (p.out_hi) {
         uint16_t hh[4], ll[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split_bf16(v[e], hh[e], ll[e]);
+        for (int e = 0; e < 4; ++e) split_bf16((p.mask_mode == 1) ? v[e] * keep[e] : v[e], hh[e], ll[e]);
         const size_t o = (size_t)orow * p.ldob + ncol;
         if (vec_ok && ((p.ldob & 3) == 0)) {
           *(u32x2_t*)(p.out_hi + o) = u32x2_t{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
@@ -266,17 +327,17 @@ constexpr int gemm_smem() {
   return stages > epi ? stages : epi;
 }
 
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV = false>
 int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
   constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE>();
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static int configured = [] {
-    return (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE>,
+    return (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE>), dim3(tiles), dim3(256), SMEM, s, *a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV>), dim3(tiles), dim3(256), SMEM, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
@@ -286,13 +347,21 @@ int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
 // Diagnostic override (tools/gemm_bench.py): -DMVP_F_BM=.. -DMVP_F_BN=.. -DMVP_F_BK=.. -DMVP_F_ST=..
 extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (!a || !a->a_hi || !a->w_hi) return MVP_EINVAL;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & 63)) return MVP_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & (a->conv ? 31 : 63))) return MVP_EINVAL;
   if ((a->lda & 7) || (a->ldw & 7)) return MVP_EINVAL;  // 16-byte aligned rows for LDS-DMA
   if (a->precision == MVP_PREC_BF16X3 && (!a->a_lo || !a->w_lo)) return MVP_EINVAL;
   if (a->precision != MVP_PREC_BF16 && a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = a->precision == MVP_PREC_BF16X3;
+  if (a->conv) {
+    if (!a->zero_page || a->cC <= 0 || (a->cC & 31) || a->ckh <= 0 || a->ckw <= 0 || a->cstride <= 0) return MVP_EINVAL;
+    if (a->K != a->ckh * a->ckw * a->cC || a->cHo <= 0 || a->cWo <= 0 || (a->M % (a->cHo * a->cWo))) return MVP_EINVAL;
+    if ((a->cH & ((1 << a->cup) - 1)) || (a->cW & ((1 << a->cup) - 1))) return MVP_EINVAL;
+    // BK = 32 keeps every tile inside one tap for any C % 32 == 0 and gives 2-3 workgroups per CU
+    if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
+    return x3 ? launch_gemm<128, 64, 32, 3, 2, true>(a, s) : launch_gemm<128, 64, 32, 1, 2, true>(a, s);
+  }
 #ifdef MVP_F_BM
   return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST>(a, s) : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST>(a, s);
 #else

@@ -141,3 +141,35 @@ extern "C" int mvp_colsum(const mvp_colsum_args* a, void* stream) {
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
+
+// ----------------------------------------------------------------------------- mask + split
+// g[M,N] fp32 (optionally gated by a byte mask) -> fp32 copy (may alias) + bf16 pair with row
+// stride ldo (>= N; pad columns are written as zeros so the buffer can feed the TN kernel).
+namespace {
+__global__ __launch_bounds__(256) void mask_split_kernel(const mvp_mask_split_args p) {
+  const int64_t total = (int64_t)p.M * p.ldo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % p.ldo);
+    const int64_t r = i / p.ldo;
+    float v = 0.f;
+    if (c < p.N) {
+      v = p.src[r * p.lds + c];
+      if (p.mask && !p.mask[r * p.ldm + c]) v = 0.f;
+      if (p.dst_f32) p.dst_f32[r * p.lds + c] = v;
+    }
+    uint16_t h, l;
+    split_bf16(v, h, l);
+    if (p.dst_hi) p.dst_hi[i] = h;
+    if (p.dst_lo) p.dst_lo[i] = l;
+  }
+}
+}  // namespace
+
+extern "C" int mvp_mask_split(const mvp_mask_split_args* a, void* stream) {
+  if (!a || !a->src || a->M <= 0 || a->N <= 0 || a->ldo < a->N || a->lds < a->N) return MVP_EINVAL;
+  int64_t g = ((int64_t)a->M * a->ldo + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(mask_split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}

@@ -68,6 +68,11 @@ class DepthHead(nn.Module):
 
     def forward(self, feats):
         """Prediction each pixel."""
+        if isinstance(self.head, DPT):
+            # the final nearest x2 of DPT commutes with the per-pixel predictor: predict at 8h x 8w,
+            # then upsample the 1-channel depth (instead of 256 channels at full resolution)
+            depth = self.predict(self.head(feats, defer_upsample=True))
+            return MF.interpolate(depth, scale_factor=2, mode="nearest")
         feats = self.head(feats)
         return self.predict(feats)
 
@@ -129,9 +134,8 @@ class Linear(nn.Module):
 
 
 class DPT(nn.Module):
-    """Reference: probes.py:309-399.  Parameter layout kept; the conv stack is not yet on the
-    HIP path (round-1 scope = linear probe); constructing it is allowed so that state dicts
-    load, calling it raises."""
+    """Reference: probes.py:309-399.  Transformer variant (4 equal-resolution taps) runs on the HIP
+    conv path (mvp/dpt.py); the ResNet-pyramid variant keeps its parameter layout and raises."""
 
     def __init__(self, input_dims, output_dim, hidden_dim=512, kernel_size=3, precision=None):
         super().__init__()
@@ -148,9 +152,21 @@ class DPT(nn.Module):
         self.out_conv = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1), nn.ReLU(True), nn.Conv2d(hidden_dim, output_dim, 3, padding=1))
         self.precision = _precision(precision)
 
-    def forward(self, feats):
+    def forward(self, feats, defer_upsample=False):
+        """Prediction each pixel.  ``defer_upsample=True`` (used by DepthHead) returns the
+        logits before the final nearest x2 (which commutes with the per-pixel predictor)."""
         assert len(feats) == 4
-        raise NotImplementedError("DPT probe forward/backward is not on the HIP path yet (see DESIGN.md, scope row P4)")
+        if self.resnet:
+            raise NotImplementedError("DPT on ResNet pyramids (3x3 input convs, bilinear x2 fusion) is not on the HIP path yet")
+        from mvp import dpt as mdpt
+
+        pack = MF.pack_features(list(feats), self.precision)
+        lq = mdpt.dpt_vit_logits(pack, self, self.precision)  # [B, 8h, 8w, K4] channels-last
+        K = self.out_conv[2].out_channels
+        y = lq[..., :K].permute(0, 3, 1, 2)
+        if defer_upsample:
+            return y
+        return MF.interpolate(y.contiguous(), scale_factor=2, mode="nearest")
 
 
 class FeatureFusionBlock(nn.Module):

@@ -47,7 +47,10 @@ class GemmArgs(C.Structure):
     _fields_ = [("a_hi", _vp), ("a_lo", _vp), ("w_hi", _vp), ("w_lo", _vp), ("bias", _vp), ("residual", _vp),
                 ("out_f32", _vp), ("out_hi", _vp), ("out_lo", _vp), ("M", _i), ("N", _i), ("K", _i),
                 ("lda", _i), ("ldw", _i), ("ldr", _i), ("ldo", _i), ("ldob", _i), ("act", _i), ("precision", _i),
-                ("row_group", _i), ("row_group_stride", _i), ("row_group_off", _i), ("res_row_mod", _i)]
+                ("row_group", _i), ("row_group_stride", _i), ("row_group_off", _i), ("res_row_mod", _i),
+                ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
+                ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
+                ("residual2", _vp)]
 
 
 class LayerNormArgs(C.Structure):
@@ -112,6 +115,26 @@ class CorrArgmaxArgs(C.Structure):
                 ("workspace", _vp), ("workspace_bytes", _i64), ("C", _i), ("h", _i), ("w", _i), ("K", _i)]
 
 
+class ConvWeightPackArgs(C.Structure):
+    _fields_ = [("w", _vp), ("out_hi", _vp), ("out_lo", _vp), ("Cout", _i), ("Cin", _i), ("kh", _i), ("kw", _i), ("mode", _i)]
+
+
+class UpsampleClArgs(C.Structure):
+    _fields_ = [("src", _vp), ("dst_f32", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("B", _i), ("H", _i), ("W", _i), ("C", _i),
+                ("f", _i), ("backward", _i)]
+
+
+class MaskSplitArgs(C.Structure):
+    _fields_ = [("src", _vp), ("mask", _vp), ("dst_f32", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("M", _i64), ("N", _i),
+                ("lds", _i), ("ldm", _i), ("ldo", _i)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [("g_hi", _vp), ("g_lo", _vp), ("x_hi", _vp), ("x_lo", _vp), ("partial", _vp), ("dw", _vp), ("zero_page", _vp),
+                ("M", _i64), ("Cout", _i), ("Cin", _i), ("ldg", _i), ("ldx", _i), ("H", _i), ("W", _i), ("Ho", _i), ("Wo", _i),
+                ("kh", _i), ("kw", _i), ("stride", _i), ("pad", _i), ("up", _i), ("splits", _i), ("accumulate", _i), ("precision", _i)]
+
+
 # every exported symbol of include/mvp_hip.h: name -> args struct (None = special signature)
 SYMBOLS = {
     "mvp_get_info": None,
@@ -136,6 +159,11 @@ SYMBOLS = {
     "mvp_colsum": ColsumArgs,
     "mvp_adamw_step": AdamWArgs,
     "mvp_corr_argmax": CorrArgmaxArgs,
+    "mvp_conv_weight_pack": ConvWeightPackArgs,
+    "mvp_upsample_nearest_cl": UpsampleClArgs,
+    "mvp_mask_split": MaskSplitArgs,
+    "mvp_gemm_tn_workspace_bytes": None,
+    "mvp_gemm_tn_conv": GemmTnArgs,
 }
 
 _lib: Optional[C.CDLL] = None
@@ -165,6 +193,8 @@ def load() -> C.CDLL:
     lib.mvp_bn_tokens_workspace_bytes.restype = _i64
     lib.mvp_colsum_workspace_bytes.argtypes = [_i, _i]
     lib.mvp_colsum_workspace_bytes.restype = _i64
+    lib.mvp_gemm_tn_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
+    lib.mvp_gemm_tn_workspace_bytes.restype = _i64
     lib.mvp_depth_loss_workspace_bytes.argtypes = [_i, _i64]
     lib.mvp_depth_loss_workspace_bytes.restype = _i64
     _lib = lib
