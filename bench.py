@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
 
 
@@ -97,8 +98,12 @@ def main():
     vsd = bb.random_vit_state_dict(seed=0)
     model = DINO(return_multilayer=True, add_norm=True, weights=vsd, precision=args.precision).to(dev)
     torch.manual_seed(0)
-    probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth",
-                      min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+    if args.probe == "linear":
+        probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth",
+                          min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+    else:
+        probe = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=512,
+                          min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
     opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}])
     total_steps = args.warmup + args.steps + 8
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 10 * total_steps, 1.5 * total_steps))
@@ -178,7 +183,7 @@ def main():
 
     # ---------------- CPU baseline leg: the oracle (port of the reference CPU path) on the host cores
     cpu = None
-    if not args.no_cpu_baseline and rank == 0 and world == 1:
+    if not args.no_cpu_baseline and rank == 0 and world == 1 and args.probe == "linear":
         from oracle import probes as oprobes
         from oracle import train as otrain
 
@@ -204,7 +209,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/LN/softmax/loss)" if args.precision == "bf16x3" else "bf16 (MFMA, fp32 accumulate)",
             "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",
-            "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(linear,k=1,bindepth) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",
+            "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(" + ("linear,k=1" if args.probe == "linear" else "dpt,k=3,hidden512") + ",bindepth) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
                        "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
             "mean_loss": round(last_loss, 5),

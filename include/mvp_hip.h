@@ -120,6 +120,7 @@ typedef struct {
    * add, mask_mode 1 gates only the bf16-pair output (out_f32 stays un-gated: skip-path gradient). */
   const uint8_t* relu_mask; uint8_t* out_mask; int ldm; int mask_mode;
   const float* residual2; /* optional second fp32 addend, same row stride ldr (fusion-block "+ skip") */
+  int act_after_res;      /* 1: apply MVP_ACT_RELU after the residual adds (ResNet bottleneck)          */
 } mvp_gemm_args;
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
 
@@ -355,6 +356,26 @@ typedef struct {
   int H, W, Ho, Wo, kh, kw, stride, pad, up;
   int splits, accumulate, precision;
 } mvp_gemm_tn_args;
+/* ------------------------------------------------------------------------------------
+ * im2col of an NCHW fp32 image for convs whose Cin is not a multiple of 32 (the ResNet 7x7/2 RGB
+ * stem, dino_res50.py:38-44): out[(b,yo,xo), (ky*kw+kx)*C + c], zero padded to ldk columns.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src; mvp_bf16* out_hi; mvp_bf16* out_lo;
+  int B, C, H, W, Ho, Wo, kh, kw, stride, pad, ldk;
+} mvp_im2col_args;
+int mvp_im2col_nchw(const mvp_im2col_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Max-pool k x k / stride on channels-last fp32 [B,H,W,C] (-inf padding, torchvision
+ * resnet50.maxpool 3x3/2 pad 1).  Outputs fp32 and/or bf16 pair.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src; float* dst_f32; mvp_bf16* dst_hi; mvp_bf16* dst_lo;
+  int B, H, W, C, Ho, Wo, k, stride, pad;
+} mvp_maxpool_cl_args;
+int mvp_maxpool_cl(const mvp_maxpool_cl_args*, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Gradient gate + split: dst = src * (mask != 0) as fp32 (may alias src) and as a bf16 pair
  * with row stride ldo >= N (pad columns zeroed) — the ReLU backward of probes.py:283-288 fused

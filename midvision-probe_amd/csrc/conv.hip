@@ -83,6 +83,60 @@ __global__ __launch_bounds__(256) void upsample_nearest_cl_bwd(const mvp_upsampl
   }
 }
 
+// ----------------------------------------------------------------------------- im2col (NCHW fp32 image -> GEMM rows)
+// For convs whose Cin is not a multiple of 32 (the 7x7/2 RGB stem): row m = (b, yo, xo),
+// col k = (ky*kw + kx)*C + c, zero padded up to ldk columns.
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const mvp_im2col_args p) {
+  const int Kc = p.kh * p.kw * p.C;
+  const int64_t total = (int64_t)p.B * p.Ho * p.Wo * p.ldk;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % p.ldk);
+    const int64_t m = i / p.ldk;
+    float v = 0.f;
+    if (k < Kc) {
+      const int c = k % p.C, t = k / p.C, ky = t / p.kw, kx = t - ky * p.kw;
+      const int xo = (int)(m % p.Wo);
+      const int64_t r = m / p.Wo;
+      const int yo = (int)(r % p.Ho);
+      const int64_t b = r / p.Ho;
+      const int y = yo * p.stride + ky - p.pad, x = xo * p.stride + kx - p.pad;
+      if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) v = p.src[((b * p.C + c) * p.H + y) * p.W + x];
+    }
+    uint16_t h, l;
+    split_bf16(v, h, l);
+    p.out_hi[i] = h;
+    if (p.out_lo) p.out_lo[i] = l;
+  }
+}
+
+// ----------------------------------------------------------------------------- max-pool (channels-last)
+__global__ __launch_bounds__(256) void maxpool_cl_kernel(const mvp_maxpool_cl_args p) {
+  const int C4 = p.C >> 2;
+  const int64_t total = (int64_t)p.B * p.Ho * p.Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int xo = (int)(r % p.Wo); r /= p.Wo;
+    const int yo = (int)(r % p.Ho);
+    const int64_t b = r / p.Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int ky = 0; ky < p.k; ++ky)
+      for (int kx = 0; kx < p.k; ++kx) {
+        const int y = yo * p.stride + ky - p.pad, x = xo * p.stride + kx - p.pad;
+        if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) continue;
+        const float4 v = ((const float4*)p.src)[((b * p.H + y) * p.W + x) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    if (p.dst_f32) ((float4*)p.dst_f32)[i] = m;
+    if (p.dst_hi) {
+      uint16_t h[4], l[4];
+      split_bf16(m.x, h[0], l[0]); split_bf16(m.y, h[1], l[1]); split_bf16(m.z, h[2], l[2]); split_bf16(m.w, h[3], l[3]);
+      ((u32x2_t*)p.dst_hi)[i] = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
+      if (p.dst_lo) ((u32x2_t*)p.dst_lo)[i] = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- TN weight-gradient GEMM
 // Tile: 128 output channels (i) x 128 input channels (j) of ONE tap; K-tile = 32 pixels.
 // LDS images [32 pixel rows][128 channels] (256-B rows), 16-B chunk c of row r stored at
@@ -284,6 +338,21 @@ extern "C" int mvp_upsample_nearest_cl(const mvp_upsample_cl_args* a, void* stre
     hipLaunchKernelGGL(upsample_nearest_cl_bwd, dim3(grid_for((int64_t)a->B * a->H * a->W * (a->C >> 2), 8192)), dim3(256), 0, s, *a);
   else
     hipLaunchKernelGGL(upsample_nearest_cl_fwd, dim3(grid_for((int64_t)a->B * a->H * a->W * a->f * a->f * (a->C >> 2), 8192)), dim3(256), 0, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_im2col_nchw(const mvp_im2col_args* a, void* stream) {
+  if (!a || !a->src || !a->out_hi || a->B <= 0 || a->C <= 0 || a->kh <= 0 || a->kw <= 0 || a->stride <= 0) return MVP_EINVAL;
+  if (a->ldk < a->kh * a->kw * a->C || a->Ho <= 0 || a->Wo <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for((int64_t)a->B * a->Ho * a->Wo * a->ldk, 16384)), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_maxpool_cl(const mvp_maxpool_cl_args* a, void* stream) {
+  if (!a || !a->src || (!a->dst_f32 && !a->dst_hi) || a->B <= 0 || a->C <= 0 || (a->C & 3) || a->k <= 0 || a->stride <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(maxpool_cl_kernel, dim3(grid_for((int64_t)a->B * a->Ho * a->Wo * (a->C >> 2), 8192)), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

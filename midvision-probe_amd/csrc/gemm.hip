@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       if (p.act == MVP_ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-      } else if (p.act == MVP_ACT_RELU) {
+      } else if (p.act == MVP_ACT_RELU && !p.act_after_res) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
@@ -290,6 +290,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       if (p.residual2) {
         const float* rp = p.residual2 + (size_t)orow * p.ldr + ncol;
         for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
+      }
+      if (p.act == MVP_ACT_RELU && p.act_after_res) {  // ResNet bottleneck: relu(conv3(x) + identity)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (p.out_f32) {
         float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;

@@ -47,7 +47,7 @@ def pack_weight(w: torch.Tensor, mode: int, precision: int, pad_cout_to: int = 0
 
 
 def conv_gemm(x: Pair, g: dict, wk: Pair, N: int, *, bias=None, act=lib.ACT_NONE, residual=None, residual2=None, out_f32=None,
-              out: Optional[Pair] = None, out_mask=None, relu_mask=None, mask_mode=0, precision=PREC_BF16X3, ldo=None, lda=None) -> None:
+              out: Optional[Pair] = None, out_mask=None, relu_mask=None, mask_mode=0, precision=PREC_BF16X3, ldo=None, lda=None, act_after_res=False) -> None:
     """Implicit-GEMM convolution: Y[B*Ho*Wo, N] = act(im2col(x) · wkᵀ + bias) (+ residual (+ residual2))."""
     M = g["B"] * g["Ho"] * g["Wo"]
     K = g["kh"] * g["kw"] * g["C"]
@@ -57,7 +57,7 @@ def conv_gemm(x: Pair, g: dict, wk: Pair, N: int, *, bias=None, act=lib.ACT_NONE
         lib.ptr(x[0]), lib.ptr(x[1]), lib.ptr(wk[0]), lib.ptr(wk[1]), lib.ptr(bias), lib.ptr(residual), lib.ptr(out_f32),
         lib.ptr(o_hi), lib.ptr(o_lo), M, N, K, lda if lda is not None else g["C"], K, ldn, ldn, ldn, act, precision, 0, 0, 0, 0,
         1, g["H"], g["W"], g["C"], g["Ho"], g["Wo"], g["kh"], g["kw"], g["stride"], g["pad"], g["up"], lib.ptr(zero_page(x[0].device)),
-        lib.ptr(relu_mask), lib.ptr(out_mask), ldn, mask_mode, lib.ptr(residual2))
+        lib.ptr(relu_mask), lib.ptr(out_mask), ldn, mask_mode, lib.ptr(residual2), int(act_after_res))
     lib.call("mvp_gemm_bias_act_res", args)
 
 

@@ -50,7 +50,7 @@ class GemmArgs(C.Structure):
                 ("row_group", _i), ("row_group_stride", _i), ("row_group_off", _i), ("res_row_mod", _i),
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
-                ("residual2", _vp)]
+                ("residual2", _vp), ("act_after_res", _i)]
 
 
 class LayerNormArgs(C.Structure):
@@ -124,6 +124,16 @@ class UpsampleClArgs(C.Structure):
                 ("f", _i), ("backward", _i)]
 
 
+class Im2colArgs(C.Structure):
+    _fields_ = [("src", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("C", _i), ("H", _i), ("W", _i), ("Ho", _i), ("Wo", _i),
+                ("kh", _i), ("kw", _i), ("stride", _i), ("pad", _i), ("ldk", _i)]
+
+
+class MaxpoolClArgs(C.Structure):
+    _fields_ = [("src", _vp), ("dst_f32", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("B", _i), ("H", _i), ("W", _i), ("C", _i),
+                ("Ho", _i), ("Wo", _i), ("k", _i), ("stride", _i), ("pad", _i)]
+
+
 class MaskSplitArgs(C.Structure):
     _fields_ = [("src", _vp), ("mask", _vp), ("dst_f32", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("M", _i64), ("N", _i),
                 ("lds", _i), ("ldm", _i), ("ldo", _i)]
@@ -162,6 +172,8 @@ SYMBOLS = {
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
     "mvp_mask_split": MaskSplitArgs,
+    "mvp_im2col_nchw": Im2colArgs,
+    "mvp_maxpool_cl": MaxpoolClArgs,
     "mvp_gemm_tn_workspace_bytes": None,
     "mvp_gemm_tn_conv": GemmTnArgs,
 }

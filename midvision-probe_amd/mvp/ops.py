@@ -72,7 +72,7 @@ def patch_gather(images: torch.Tensor, out: Pair, P: int, gh: int, gw: int, pad_
 
 def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, out_f32=None, out: Optional[Pair] = None,
          act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
-         row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0) -> None:
+         row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0) -> None:
     """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res)."""
     o_hi, o_lo = out if out is not None else (None, None)
     args = lib.GemmArgs(
@@ -81,6 +81,9 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
         lda if lda is not None else K, ldw if ldw is not None else K,
         ldr if ldr is not None else N, ldo if ldo is not None else N, ldob if ldob is not None else N,
         act, precision, row_group, row_group_stride, row_group_off, res_row_mod)
+    args.act_after_res = int(act_after_res)
+    if out_mask is not None:
+        args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
     if _TRACE is None:
         lib.call("mvp_gemm_bias_act_res", args)
         return
