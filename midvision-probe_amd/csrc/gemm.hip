@@ -260,14 +260,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      if (p.out_mask) {  // forward: remember which outputs the activation kept (ReLU backward gate)
+      auto write_mask = [&]() {  // forward: remember which outputs the ReLU kept (its backward gate)
         uint8_t* mo = p.out_mask + (size_t)orow * p.ldm + ncol;
         if (vec_ok && ((p.ldm & 3) == 0)) {
           *(uint32_t*)mo = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 0x100u : 0u) | (v[2] > 0.f ? 0x10000u : 0u) | (v[3] > 0.f ? 0x1000000u : 0u);
         } else {
           for (int e = 0; e < 4; ++e) if (ncol + e < p.N) mo[e] = v[e] > 0.f ? 1 : 0;
         }
-      }
+      };
+      if (p.out_mask && !p.act_after_res) write_mask();
       float keep[4] = {1.f, 1.f, 1.f, 1.f};
       if (p.relu_mask) {  // backward of ReLU: gate by the saved byte mask
         const uint8_t* mp = p.relu_mask + (size_t)orow * p.ldm + ncol;
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       if (p.act == MVP_ACT_RELU && p.act_after_res) {  // ResNet bottleneck: relu(conv3(x) + identity)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (p.out_mask) write_mask();  // gate of the post-residual ReLU (pre-activation fusion blocks)
       }
       if (p.out_f32) {
         float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;

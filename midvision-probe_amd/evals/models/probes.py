@@ -126,10 +126,11 @@ class Linear(nn.Module):
     def forward(self, feats):
         if type(feats) is not list and not isinstance(feats, (list, tuple)):
             feats = [feats]
-        if self.kernel_size != 1:
-            raise NotImplementedError("Linear probe with kernel_size > 1 is not on the HIP path yet (k=1 is the linear-probe headline)")
         K = self.conv.out_channels
-        lq = MF.linear_head_k1(feats, self.conv.weight, self.conv.bias, self.precision)  # [B,4h,4w,K4]
+        if self.kernel_size != 1:
+            lq = MF.linear_head_kxk(feats, self.conv.weight, self.conv.bias, self.precision)
+        else:
+            lq = MF.linear_head_k1(feats, self.conv.weight, self.conv.bias, self.precision)  # [B,4h,4w,K4]
         return lq[..., :K].permute(0, 3, 1, 2)  # NCHW view of the channels-last logits
 
 
@@ -157,11 +158,24 @@ class DPT(nn.Module):
         logits before the final nearest x2 (which commutes with the per-pixel predictor)."""
         assert len(feats) == 4
         if self.resnet:
-            raise NotImplementedError("DPT on ResNet pyramids (3x3 input convs, bilinear x2 fusion) is not on the HIP path yet")
-        from mvp import dpt as mdpt
+            from mvp import dpt_res, ops
 
-        pack = MF.pack_features(list(feats), self.precision)
-        lq = mdpt.dpt_vit_logits(pack, self, self.precision)  # [B, 8h, 8w, K4] channels-last
+            B = feats[0].shape[0]
+            toks, dims = [], []
+            for f in feats:  # NCHW fp32 pyramid -> channels-last bf16 pairs (operands of the 3x3 input convs)
+                if not f.is_cuda:
+                    raise lib.MvpError("probe features must be device tensors (no CPU fallback)")
+                _, C, H, W = f.shape
+                tok = ops.empty_pair((B * H * W, C), self.precision, f.device)
+                ops.pack_nchw_tokens(f.contiguous().float(), B, C, H * W, tok=tok, ld_tok=C, col_off=0)
+                toks.append(tok)
+                dims.append((C, H, W))
+            lq = dpt_res.dpt_res_logits(toks, dims, B, self, self.precision)  # [B, 2*H_0, 2*W_0, K4]
+        else:
+            from mvp import dpt as mdpt
+
+            pack = MF.pack_features(list(feats), self.precision)
+            lq = mdpt.dpt_vit_logits(pack, self, self.precision)  # [B, 8h, 8w, K4] channels-last
         K = self.out_conv[2].out_channels
         y = lq[..., :K].permute(0, 3, 1, 2)
         if defer_upsample:

@@ -139,6 +139,61 @@ def linear_head_k1(feats: Sequence[torch.Tensor], weight: torch.Tensor, bias: to
     return _LinearHeadK1.apply(weight, bias, pack, precision)
 
 
+class _LinearHeadKxK(torch.autograd.Function):
+    """probes.py:427-432 for kernel_size > 1: the conv no longer commutes with the resample, so the
+    features ARE upsampled (bilinear x4, as the reference does) into a channels-last bf16 pair and the
+    k x k conv runs as an implicit GEMM; weight gradient through the TN split-K kernel."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, feats, precision):
+        from . import conv as cv
+
+        B, _, h, w = feats[0].shape
+        dev = weight.device
+        K, Ctot, k, _ = weight.shape
+        if Ctot % 128:
+            raise lib.MvpError("Linear(k>1) on the HIP path needs sum(feat_dim) % 128 == 0")
+        H4, W4 = 4 * h, 4 * w
+        M = B * H4 * W4
+        up = ops.empty_pair((M, Ctot), precision, dev)
+        off = 0
+        for f in feats:  # bilinear x4 per map (planar kernel), packed channels-last at its channel offset
+            C = int(f.shape[1])
+            big = torch.empty(B, C, H4, W4, dtype=torch.float32, device=dev)
+            ops.resize(f.contiguous().float(), big, B * C, h, w, H4, W4, lib.RESIZE_BILINEAR, scale_h=4.0, scale_w=4.0)
+            ops.pack_nchw_tokens(big, B, C, H4 * W4, tok=up, ld_tok=Ctot, col_off=off)
+            off += C
+        K4 = (K + 3) // 4 * 4
+        g = cv.geom(B, H4, W4, Ctot, k, k, 1, k // 2)
+        b4 = torch.cat([bias.detach().float(), bias.new_zeros(K4 - K).float()]) if K4 != K else bias.detach().float().contiguous()
+        lq = torch.empty(B, H4, W4, K4, dtype=torch.float32, device=dev)
+        cv.conv_gemm(up, g, cv.pack_weight(weight, 0, precision, pad_cout_to=K4), K4, bias=b4, out_f32=lq, precision=precision)
+        ctx.up, ctx.g, ctx.cfg = up, g, (K, K4, M, precision)
+        ctx.wshape = weight.shape
+        return lq
+
+    @staticmethod
+    def backward(ctx, glq):
+        from . import conv as cv
+
+        K, K4, M, pr = ctx.cfg
+        dev = glq.device
+        gl = glq.contiguous().float().reshape(M, K4)
+        LG = (K4 + 127) // 128 * 128
+        gP = cv.mask_split(gl, None, M, K4, ldo=LG, precision=pr)
+        dW = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
+        cv.conv_dw(gP, LG, ctx.up, ctx.g["C"], ctx.g, K, dW, precision=pr)
+        db = torch.empty(K4, dtype=torch.float32, device=dev)
+        ops.colsum(gl, db, M, K4)
+        return dW, db[:K].contiguous(), None, None
+
+
+def linear_head_kxk(feats: Sequence[torch.Tensor], weight: torch.Tensor, bias: torch.Tensor, precision: int) -> torch.Tensor:
+    for f in feats:
+        _need_cuda(f, "probe features")
+    return _LinearHeadKxK.apply(weight, bias, list(feats), precision)
+
+
 # --------------------------------------------------------------------------- depth predictors
 class _DepthPredict(torch.autograd.Function):
     @staticmethod

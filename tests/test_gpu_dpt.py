@@ -205,3 +205,30 @@ def test_dpt_probe_fwd_bwd_vs_oracle(dev, kind):
         a64, b64 = p.grad.double().cpu().flatten(), sd_r[n].grad.double().flatten()
         assert 1 - float(a64 @ b64 / (a64.norm() * b64.norm())) < 2e-3, n
     print(f"\n[dpt {kind}] worst param-grad rel-L2 = {worst:.2e}")
+
+
+@pytest.mark.parametrize("pt", ["bindepth", "sigdepth"])
+def test_linear_probe_k3_vs_oracle(dev, pt):
+    """probes.py:417-432 with kernel_size=3 (no conv/resample commutation: explicit bilinear x4 + 3x3 conv)."""
+    from evals.models.probes import DepthHead
+    from oracle import probes as oprobes
+
+    C, B, h, w = 32, 2, 5, 7
+    g = torch.Generator().manual_seed(9)
+    feats = [torch.randn(B, C, h, w, generator=g) for _ in range(4)]
+    odim = 256 if pt == "bindepth" else 1
+    probe = DepthHead(feat_dim=[C] * 4, head_type="linear", kernel_size=3, prediction_type=pt)
+    assert probe.name == f"{pt}_linear_k3"
+    sd = oprobes.make_linear_head_weights([C] * 4, odim, 3, seed=8)
+    probe.load_state_dict(sd, strict=True)
+    probe = probe.to(dev)
+    y = probe([f.to(dev) for f in feats])
+    sd_r = {n: t.clone().requires_grad_(True) for n, t in sd.items()}
+    y_ref = oprobes.depth_head(sd_r, feats, "linear", 3, pt)
+    gy = torch.randn(y_ref.shape, generator=g)
+    (y_ref * gy).sum().backward()
+    (y * gy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_l2(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 2e-5
+    for n, p in probe.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), sd_r[n].grad.numpy()) < (5e-3 if pt == "bindepth" else 1e-4), n
