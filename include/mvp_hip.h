@@ -357,6 +357,22 @@ typedef struct {
   int splits, accumulate, precision;
 } mvp_gemm_tn_args;
 /* ------------------------------------------------------------------------------------
+ * Fused tail of the linear depth-bin probe: bilinear x f (align_corners=False) of the
+ * token-resolution logits L0 [B,h,w,K] fused with DepthBinPrediction (probes.py:431 + :176-200).
+ * The upsampled logits are never materialised; gate holds 1 bit per (pixel, bin) = [logit > 0].
+ *   fwd: l0 -> depth [B*hf*wf], inv_sum [B*hf*wf], gate [B*hf*wf, K/8]
+ *   bwd: grad_depth, depth, inv_sum, gate -> grad_l0 [B,h,w,K]          (K % 8 == 0)
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* l0; float* depth; float* inv_sum; uint8_t* gate;
+  const float* grad_depth; float* grad_l0;
+  int B, h, w, K, f;
+  float min_depth, max_depth;
+} mvp_linear_bins_args;
+int mvp_linear_bins_fwd(const mvp_linear_bins_args*, void* stream);
+int mvp_linear_bins_bwd(const mvp_linear_bins_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * im2col of an NCHW fp32 image for convs whose Cin is not a multiple of 32 (the ResNet 7x7/2 RGB
  * stem, dino_res50.py:38-44): out[(b,yo,xo), (ky*kw+kx)*C + c], zero padded to ldk columns.
  * ---------------------------------------------------------------------------------- */

@@ -102,8 +102,11 @@ constexpr int ADJ_MAXW = 24;  // candidate columns whose weights are cached in r
 __global__ __launch_bounds__(256) void resize_bwd_planar(const mvp_resize_args p) {
   const float sh = src_scale(p.Hi, p.Ho, p.align_corners, p.scale_h);
   const float sw = src_scale(p.Wi, p.Wo, p.align_corners, p.scale_w);
+  // 8 lanes cooperate on one input element (candidate rows strided by 8, xor-shuffle reduce): the
+  // planar adjoint runs on few, small planes (B x 56 x 56 depth maps), i.e. it is latency-bound.
   const int64_t total = (int64_t)p.planes * p.Hi * p.Wi;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  const int sub = threadIdx.x & 7;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; i < total; i += ((int64_t)gridDim.x * 256) >> 3) {
     const int ix = (int)(i % p.Wi);
     const int64_t r = i / p.Wi;
     const int iy = (int)(r % p.Hi);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void resize_bwd_planar(const mvp_resize_args p
       for (int k = 0; k < ADJ_MAXW; ++k) wxs[k] = (k < nx) ? adj_w(p.mode, p.align_corners, sw, xlo + k, p.Wi, ix) : 0.f;
     }
     float acc = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
+    for (int oy = ylo + sub; oy <= yhi; oy += 8) {
       const float wy = adj_w(p.mode, p.align_corners, sh, oy, p.Hi, iy);
       if (wy == 0.f) continue;
       const float* grow = g + (size_t)oy * p.Wo + xlo;
@@ -134,7 +137,10 @@ __global__ __launch_bounds__(256) void resize_bwd_planar(const mvp_resize_args p
       }
       acc += wy * rowacc;
     }
-    p.dst[i] = acc;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) p.dst[i] = acc;
   }
 }
 
@@ -245,7 +251,7 @@ extern "C" int mvp_resize_bwd(const mvp_resize_args* a, void* stream) {
   if (a->channels_last)
     hipLaunchKernelGGL(resize_bwd_cl, dim3(grid_for((int64_t)a->planes * a->Hi * a->Wi * (a->C >> 2))), dim3(256), 0, s, *a);
   else
-    hipLaunchKernelGGL(resize_bwd_planar, dim3(grid_for((int64_t)a->planes * a->Hi * a->Wi)), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(resize_bwd_planar, dim3(grid_for((int64_t)a->planes * a->Hi * a->Wi * 8)), dim3(256), 0, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

@@ -73,6 +73,14 @@ class DepthHead(nn.Module):
             # then upsample the 1-channel depth (instead of 256 channels at full resolution)
             depth = self.predict(self.head(feats, defer_upsample=True))
             return MF.interpolate(depth, scale_factor=2, mode="nearest")
+        if (isinstance(self.head, Linear) and self.head.kernel_size == 1 and isinstance(self.predict, DepthBinPrediction)
+                and self.head.conv.out_channels % 8 == 0):
+            # fused GEMM -> [bilinear x4 + bin expectation]: same arithmetic as head -> predict, without
+            # materialising the x4-upsampled logits (mvp/functional.py:_LinearBinsHead)
+            if type(feats) is not list and not isinstance(feats, (list, tuple)):
+                feats = [feats]
+            return MF.linear_bins_head(feats, self.head.conv.weight, self.head.conv.bias, self.head.precision,
+                                       self.predict.n_bins, self.predict.min_depth, self.predict.max_depth)
         feats = self.head(feats)
         return self.predict(feats)
 

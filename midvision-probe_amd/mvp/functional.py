@@ -139,6 +139,64 @@ def linear_head_k1(feats: Sequence[torch.Tensor], weight: torch.Tensor, bias: to
     return _LinearHeadK1.apply(weight, bias, pack, precision)
 
 
+class _LinearBinsHead(torch.autograd.Function):
+    """DepthHead(linear, k=1, bindepth) in one piece (probes.py:153-157,176-200,427-432):
+    GEMM at token resolution -> fused [bilinear x4 + bin expectation] kernel that keeps one gate
+    bit per logit instead of the 16x larger upsampled logits -> depth [B,1,4h,4w]."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, pack: PackedFeatures, precision: int, n_bins: int, min_depth: float, max_depth: float):
+        K, Ctot = weight.shape[0], pack.Ctot
+        dev = weight.device
+        w2 = weight.detach().reshape(K, Ctot).float()
+        if pack.Cpad != Ctot:
+            wpad = w2.new_zeros(K, pack.Cpad)
+            wpad[:, :Ctot] = w2
+            w2 = wpad
+        wp = ops.split_bf16(w2.contiguous(), precision)
+        l0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
+        ops.gemm(pack.tok, wp, pack.M, K, pack.Cpad, bias=bias.detach().float().contiguous(), out_f32=l0, precision=precision)
+        B, h, w = pack.B, pack.h, pack.w
+        P = B * 16 * h * w
+        depth = torch.empty(B, 1, 4 * h, 4 * w, dtype=torch.float32, device=dev)
+        inv = torch.empty(P, dtype=torch.float32, device=dev)
+        gate = torch.empty(P, K // 8, dtype=torch.uint8, device=dev)
+        a = lib.LinearBinsArgs(lib.ptr(l0), lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), None, None, B, h, w, K, 4, min_depth, max_depth)
+        lib.call("mvp_linear_bins_fwd", a)
+        ctx.pack, ctx.precision, ctx.cfg = pack, precision, (K, min_depth, max_depth)
+        ctx.wshape, ctx.generation = weight.shape, pack.generation
+        ctx.save_for_backward(depth, inv, gate)
+        return depth
+
+    @staticmethod
+    def backward(ctx, gd):
+        depth, inv, gate = ctx.saved_tensors
+        pack, pr = ctx.pack, ctx.precision
+        K, mn, mx = ctx.cfg
+        B, h, w, Ctot = pack.B, pack.h, pack.w, pack.Ctot
+        dev = gd.device
+        if pack.generation != ctx.generation:
+            raise lib.MvpError("linear head backward: the backbone ran again before this backward and overwrote the packed "
+                               "features of this step (call backward before the next model(images))")
+        gl0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
+        a = lib.LinearBinsArgs(None, lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), lib.ptr(gd.contiguous().float()), lib.ptr(gl0), B, h, w, K, 4, mn, mx)
+        lib.call("mvp_linear_bins_bwd", a)
+        gT = pack.scratch.get(("gT", K))
+        if gT is None:
+            gT = pack.scratch[("gT", K)] = ops.zeros_pair((K, pack.Mpad), pr, dev)
+        ops.pack_nchw_tokens(gl0, 1, pack.M, K, tok=gT, ld_tok=pack.Mpad, col_off=0)
+        dW = torch.empty(K, Ctot, dtype=torch.float32, device=dev)
+        ops.gemm(gT, pack.tokT, K, Ctot, pack.Mpad, out_f32=dW, precision=pr)
+        db = torch.empty(K, dtype=torch.float32, device=dev)
+        ops.colsum(gl0, db, pack.M, K)
+        return dW.reshape(ctx.wshape), db, None, None, None, None, None
+
+
+def linear_bins_head(feats: Sequence[torch.Tensor], weight, bias, precision: int, n_bins: int, min_depth: float, max_depth: float) -> torch.Tensor:
+    pack = pack_features(list(feats), precision)
+    return _LinearBinsHead.apply(weight, bias, pack, precision, n_bins, float(min_depth), float(max_depth))
+
+
 class _LinearHeadKxK(torch.autograd.Function):
     """probes.py:427-432 for kernel_size > 1: the conv no longer commutes with the resample, so the
     features ARE upsampled (bilinear x4, as the reference does) into a channels-last bf16 pair and the

@@ -124,6 +124,11 @@ class UpsampleClArgs(C.Structure):
                 ("f", _i), ("backward", _i)]
 
 
+class LinearBinsArgs(C.Structure):
+    _fields_ = [("l0", _vp), ("depth", _vp), ("inv_sum", _vp), ("gate", _vp), ("grad_depth", _vp), ("grad_l0", _vp),
+                ("B", _i), ("h", _i), ("w", _i), ("K", _i), ("f", _i), ("min_depth", _f), ("max_depth", _f)]
+
+
 class Im2colArgs(C.Structure):
     _fields_ = [("src", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("C", _i), ("H", _i), ("W", _i), ("Ho", _i), ("Wo", _i),
                 ("kh", _i), ("kw", _i), ("stride", _i), ("pad", _i), ("ldk", _i)]
@@ -172,6 +177,8 @@ SYMBOLS = {
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
     "mvp_mask_split": MaskSplitArgs,
+    "mvp_linear_bins_fwd": LinearBinsArgs,
+    "mvp_linear_bins_bwd": LinearBinsArgs,
     "mvp_im2col_nchw": Im2colArgs,
     "mvp_maxpool_cl": MaxpoolClArgs,
     "mvp_gemm_tn_workspace_bytes": None,
