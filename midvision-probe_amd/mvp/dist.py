@@ -23,13 +23,15 @@ def env_setup(backend: str = "nccl"):
     """torchrun-style: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", rank))
+    # Rehearsal overrides (1-GPU boxes): MVP_DIST_BACKEND=gloo + MVP_FORCE_DEVICE=0 let several ranks share
+    # one card to exercise the multi-rank control flow; production = nccl (RCCL), one rank per GPU.
+    backend = os.environ.get("MVP_DIST_BACKEND", backend)
+    dev = int(os.environ.get("MVP_FORCE_DEVICE", local))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif backend == "nccl" and torch.cuda.is_available():
-        torch.cuda.set_device(local)
     return rank, local, world
 
 
