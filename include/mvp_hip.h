@@ -357,6 +357,28 @@ typedef struct {
   int splits, accumulate, precision;
 } mvp_gemm_tn_args;
 /* ------------------------------------------------------------------------------------
+ * Validation metrics, fused masked reductions per image:
+ *   depth : evaluate_depth global metrics (evals/utils/metrics.py:106-178): out[b] =
+ *           {d1,d2,d3,rmse,mean_pred,std_pred,variance_pred,mean_gt,std_gt,variance_gt,variance_ratio,n_valid};
+ *           scale_invariant != 0 first solves match_scale_and_shift (metrics.py:742-780) per image and
+ *           writes (scale, shift) to scale_shift[b].  pred/gt [B, HW].
+ *   snorm : evaluate_surface_norm global metrics (metrics.py:397-440): out[b] = {d1,d2,d3,rmse_deg,n_valid};
+ *           pred [B,Cp>=3,HW] (first 3 channels), gt [B,3,HW], valid = |gt|_1 > 0.
+ * workspace >= mvp_metrics_workspace_bytes(B).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* pred; const float* gt; float* out; float* scale_shift;
+  void* workspace; int64_t workspace_bytes; int B; int64_t HW; int scale_invariant;
+} mvp_depth_metrics_args;
+typedef struct {
+  const float* pred; const float* gt; float* out;
+  void* workspace; int64_t workspace_bytes; int B; int Cp; int64_t HW; float t1, t2, t3;
+} mvp_snorm_metrics_args;
+int64_t mvp_metrics_workspace_bytes(int B);
+int mvp_depth_metrics(const mvp_depth_metrics_args*, void* stream);
+int mvp_snorm_metrics(const mvp_snorm_metrics_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused tail of the linear depth-bin probe: bilinear x f (align_corners=False) of the
  * token-resolution logits L0 [B,h,w,K] fused with DepthBinPrediction (probes.py:431 + :176-200).
  * The upsampled logits are never materialised; gate holds 1 bit per (pixel, bin) = [logit > 0].

@@ -124,6 +124,16 @@ class UpsampleClArgs(C.Structure):
                 ("f", _i), ("backward", _i)]
 
 
+class DepthMetricsArgs(C.Structure):
+    _fields_ = [("pred", _vp), ("gt", _vp), ("out", _vp), ("scale_shift", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
+                ("B", _i), ("HW", _i64), ("scale_invariant", _i)]
+
+
+class SnormMetricsArgs(C.Structure):
+    _fields_ = [("pred", _vp), ("gt", _vp), ("out", _vp), ("workspace", _vp), ("workspace_bytes", _i64), ("B", _i), ("Cp", _i),
+                ("HW", _i64), ("t1", _f), ("t2", _f), ("t3", _f)]
+
+
 class LinearBinsArgs(C.Structure):
     _fields_ = [("l0", _vp), ("depth", _vp), ("inv_sum", _vp), ("gate", _vp), ("grad_depth", _vp), ("grad_l0", _vp),
                 ("B", _i), ("h", _i), ("w", _i), ("K", _i), ("f", _i), ("min_depth", _f), ("max_depth", _f)]
@@ -177,6 +187,9 @@ SYMBOLS = {
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
     "mvp_mask_split": MaskSplitArgs,
+    "mvp_metrics_workspace_bytes": None,
+    "mvp_depth_metrics": DepthMetricsArgs,
+    "mvp_snorm_metrics": SnormMetricsArgs,
     "mvp_linear_bins_fwd": LinearBinsArgs,
     "mvp_linear_bins_bwd": LinearBinsArgs,
     "mvp_im2col_nchw": Im2colArgs,
@@ -212,6 +225,8 @@ def load() -> C.CDLL:
     lib.mvp_bn_tokens_workspace_bytes.restype = _i64
     lib.mvp_colsum_workspace_bytes.argtypes = [_i, _i]
     lib.mvp_colsum_workspace_bytes.restype = _i64
+    lib.mvp_metrics_workspace_bytes.argtypes = [_i]
+    lib.mvp_metrics_workspace_bytes.restype = _i64
     lib.mvp_gemm_tn_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
     lib.mvp_gemm_tn_workspace_bytes.restype = _i64
     lib.mvp_depth_loss_workspace_bytes.argtypes = [_i, _i64]

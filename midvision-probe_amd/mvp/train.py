@@ -74,3 +74,27 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
             train_loss += loss.item()  # the reference syncs every step too (train_depth.py:143)
         history.append(train_loss / max(len(train_loader), 1))
     return history
+
+
+def validate(model, probe, loader, loss_fn, verbose=True, scale_invariant=False, aggregate=True):
+    """Reference: validate(), train_depth.py:357-483 (global metrics; W&B / per-image dumps /
+    segment breakdowns are outside the hot path).  Returns (mean loss, {metric: mean})."""
+    from evals.utils.metrics import evaluate_depth, match_scale_and_shift
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    total_loss, sums, count = 0.0, {}, 0
+    with torch.no_grad():
+        for batch in loader:
+            images = batch["image"].to(dev)
+            target = batch["depth"].to(dev).contiguous()
+            feats = model(images)
+            pred = probe(feats)
+            pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
+            loss = loss_fn(pred, target)
+            total_loss += loss.item()
+            gm, _, _ = evaluate_depth(pred, target, None, scale_invariant=scale_invariant, is_navi=True)
+            for k, v in gm.items():
+                sums.setdefault(k, []).append(v.reshape(-1))
+            count += 1
+    metrics = {k: (torch.cat(v).mean().item() if aggregate else torch.cat(v)) for k, v in sums.items()}
+    return total_loss / max(count, 1), metrics

@@ -59,8 +59,15 @@ class PackedFeatures:
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
 
 
+def _ver(t: torch.Tensor) -> int:
+    try:
+        return t._version
+    except RuntimeError:  # inference tensors do not track a version counter
+        return -1
+
+
 def register_pack(maps: Sequence[torch.Tensor], pack: PackedFeatures) -> None:
-    pack.sources = [(m.data_ptr(), m._version) for m in maps]
+    pack.sources = [(m.data_ptr(), _ver(m)) for m in maps]
     _PACK_REGISTRY.clear()  # single most-recent entry: the probe consumes features right after the backbone
     _PACK_REGISTRY[maps[0].data_ptr()] = pack
 
@@ -74,7 +81,7 @@ def lookup_pack(maps: Sequence[torch.Tensor]) -> Optional[PackedFeatures]:
     if pack is None or len(pack.sources) != len(maps):
         return None
     for m, (p, v) in zip(maps, pack.sources):
-        if m.data_ptr() != p or m._version != v:
+        if m.data_ptr() != p or _ver(m) != v:
             return None
     return pack
 

@@ -305,11 +305,52 @@ def golden_step(vt, pr, ls, op):
     print("step_tiny", losses)
 
 
+def golden_metrics():
+    """G7: evaluate_depth (global metrics, scale-aware and scale-invariant), match_scale_and_shift,
+    evaluate_surface_norm (global) from evals/utils/metrics.py.  That module needs ``loguru`` (absent):
+    a 3-line stub logger is registered first."""
+    lg = types.ModuleType("loguru")
+
+    class _L:
+        def warning(self, *a, **k):
+            pass
+
+        info = warning
+
+    lg.logger = _L()
+    sys.modules.setdefault("loguru", lg)
+    mt = importlib.import_module("evals.utils.metrics")
+    out = {}
+    g = torch.Generator().manual_seed(400)
+    B, H, W = 5, 37, 41
+    pr = torch.rand(B, 1, H, W, generator=g) * 9 + 0.05
+    gt = torch.rand(B, 1, H, W, generator=g) * 9 + 0.05
+    gt[torch.rand(gt.shape, generator=g) < 0.2] = 0
+    gt[4] = 0  # an image without any valid pixel (num_valid -> 1e-6 path)
+    seg = torch.zeros(B, H, W, dtype=torch.long)
+    out["pred"], out["gt"] = _np(pr), _np(gt)
+    for tag, si in (("sa", False), ("si", True)):
+        gm = mt.evaluate_depth(pr, gt, seg, scale_invariant=si, is_navi=True)[0]
+        for k, v in gm.items():
+            out[f"{tag}_{k}"] = _np(v.reshape(B))
+    out["matched"] = _np(mt.match_scale_and_shift(pr, gt))
+    sn = torch.randn(B, 4, H, W, generator=g)
+    sg = torch.randn(B, 3, H, W, generator=g)
+    sg = sg / sg.norm(dim=1, keepdim=True)
+    sg[:, :, :5] = 0  # invalid rows (|gt| sum == 0)
+    out["sn_pred"], out["sn_gt"] = _np(sn), _np(sg)
+    sm = mt.evaluate_surface_norm(sn, sg, seg, is_navi=True)[0]
+    for k, v in sm.items():
+        out[f"sn_{k}"] = _np(v.reshape(B))
+    np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+    print("metrics", {k: v.shape for k, v in out.items() if k.startswith("sa_")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     vt, pr, ls, op = _load_reference()
-    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step"]
+    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics"]
     if "vit_tiny" in which:
         golden_vit_tiny(vt)
     if "vit_tiny128" in which:
@@ -324,6 +365,8 @@ def main():
         golden_step(vt, pr, ls, op)
     if "vit_base" in which:
         golden_vit_base(vt)
+    if "metrics" in which:
+        golden_metrics()
 
 
 if __name__ == "__main__":
