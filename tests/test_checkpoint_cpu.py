@@ -1,0 +1,26 @@
+"""N2: checkpoint round trip in the reference's {"cfg","model","probe"} format, incl. loading a
+reference-style DDP checkpoint ("module." prefixes) — host logic only, runs on CPU."""
+import torch
+
+from oracle import probes as oprobes
+
+
+def test_probe_checkpoint_roundtrip(tmp_path):
+    from evals.models.probes import DepthHead
+    from mvp import checkpoint as ck
+
+    probe = DepthHead(feat_dim=[32] * 4, head_type="dpt", prediction_type="bindepth", hidden_dim=16, kernel_size=3)
+    sd = oprobes.make_dpt_weights([32] * 4, 256, hidden=16, k=3, seed=1)
+    probe.load_state_dict(sd, strict=True)
+    model = torch.nn.Linear(2, 2)
+    path = ck.save_checkpoint(str(tmp_path / "exp" / "ckpt.pth"), {"note": "x"}, model, probe)
+    blob = torch.load(path, weights_only=False)
+    assert set(blob) == {"cfg", "model", "probe"} and set(blob["probe"]) == set(sd)
+    # reference checkpoints written from DDP-wrapped modules carry "module." prefixes
+    blob["probe"] = {"module." + k: v for k, v in blob["probe"].items()}
+    torch.save(blob, path)
+    probe2 = DepthHead(feat_dim=[32] * 4, head_type="dpt", prediction_type="bindepth", hidden_dim=16, kernel_size=3)
+    ck.load_checkpoint(path, model, probe2)
+    for k, v in probe2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert probe2.name == "bindepth_dpt_k3"
