@@ -125,3 +125,35 @@ class ResNetBackbone(nn.Module):
                 for i in self.multilayers:
                     self.batchnorms[i].num_batches_tracked += 1
         return outs[0] if len(outs) == 1 else outs
+
+
+def make_ssl_resnet50(class_name: str, tag: str, prefixes, local_names, ref: str):
+    """Factory for the ResNet-50 SSL wrappers that share the reference's template
+    (arch, return_layers, output, return_multilayer, add_norm, return_kqv, fixed_size, mode_selected, return_cls):
+    they differ only in the checkpoint-name tag and in the state-dict prefix to strip."""
+
+    def __init__(self, arch="resnet50", return_layers=None, output="dense", return_multilayer=False, add_norm=False, return_kqv=False,
+                 fixed_size=480, mode_selected="k", return_cls=False, weights=None, precision=None, init_seed=0):
+        ResNetBackbone.__init__(self)
+        assert arch == "resnet50", f"Invalid arch: {arch}"
+        if return_kqv:
+            raise NotImplementedError("return_kqv is outside the hot path")
+        self.arch = arch
+        self.return_cls = return_cls
+        sd = weights
+        if sd is None:
+            path = bb.find_checkpoint(*local_names)
+            if path is not None:
+                sd = bb.load_checkpoint_file(path)
+                for pre in prefixes:  # prepare_state_dict(remove_prefix=...), util.py:106-120
+                    if any(k.startswith(pre) for k in sd):
+                        sd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+                sd = {k: v for k, v in sd.items() if not (k.startswith("fc.") or k.startswith("head."))}
+            else:
+                warnings.warn(f"no local checkpoint for {class_name}: using seeded random init (seed={init_seed})")
+                sd = random_resnet50_state_dict(init_seed)
+        self._setup(sd, output, return_layers, return_multilayer, add_norm, fixed_size, precision)
+        self.checkpoint_name = f"{tag}_{arch}_{output}_{self.return_layers}"
+        self.return_kqv, self.mode_selected = return_kqv, mode_selected
+
+    return type(class_name, (ResNetBackbone,), {"__init__": __init__, "__doc__": f"Drop-in for {ref} (same ResNet-50 template as mocov3_res50.py)."})

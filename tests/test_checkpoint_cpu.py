@@ -24,3 +24,21 @@ def test_probe_checkpoint_roundtrip(tmp_path):
     for k, v in probe2.state_dict().items():
         assert torch.equal(v, sd[k]), k
     assert probe2.name == "bindepth_dpt_k3"
+
+
+def test_ssl_resnet50_wrapper_surface():
+    """N4: the other ResNet-50 SSL wrappers share the template: constructor surface + attributes (CPU, no compute)."""
+    import importlib
+    import warnings
+
+    for mod, cls, name in (("barlowtwins", "BARLOWTWINS", "$barlowtwins$_resnet50_dense_[1, 2, 3, 4]"),
+                           ("swav", "SWAV", "$swav$_resnet50_dense_[1, 2, 3, 4]"),
+                           ("simclr", "SIMCLR", "simclr_resnet50_dense_[1, 2, 3, 4]"),
+                           ("deepclusterv2", "DEEPCLUSTERV2", "$deepcluster_v2$_resnet50_dense_[1, 2, 3, 4]")):
+        K = getattr(importlib.import_module(f"evals.models.{mod}"), cls)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = K(arch="resnet50", output="dense", return_layers=[1, 2, 3, 4], add_norm=True, return_multilayer=True)
+        assert m.checkpoint_name == name and m.layer == "1-2-3-4" and m.patch_size == 0
+        assert m.feat_dim == [(256, 120), (512, 60), (1024, 30), (2048, 15)] and len(m.batchnorms) == 5
+        assert "model.layer4.2.conv3.weight" in m.state_dict()
