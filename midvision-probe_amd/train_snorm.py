@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Entry point mirroring the reference's train_snorm.py (train_snorm.py:86-120 loop; bicubic upsample,
+uncertainty-aware angular loss, SurfaceNormalHead) on synthetic NYU-shaped batches.
+
+    python train_snorm.py backbone=dino_b16 +backbone.return_multilayer=True probe=snorm_dpt batch_size=8
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import torch  # noqa: E402
+
+from mvp import checkpoint, config  # noqa: E402
+from mvp import dist as mdist  # noqa: E402
+from mvp.optim import FlatAdamW  # noqa: E402
+from mvp.train import train_snorm_step  # noqa: E402
+
+
+def batches(n, B, hw, rank):
+    """Batch dict contract of evals/datasets/nyu.py:131-138: image, depth (mask = depth > 0), snorm."""
+    for s in range(n):
+        g = torch.Generator().manual_seed(1000 * rank + s)
+        img = torch.randn(B, 3, *hw, generator=g)
+        d = torch.rand(B, 1, *hw, generator=g) * 9.9 + 0.05
+        d[torch.rand(B, 1, *hw, generator=g) < 0.1] = 0
+        nrm = torch.randn(B, 3, *hw, generator=g)
+        yield {"image": img, "depth": d, "snorm": nrm / nrm.norm(dim=1, keepdim=True).clamp_min(1e-6)}
+
+
+def main(argv):
+    from evals.utils.metrics import evaluate_surface_norm
+    from evals.utils.optim import cosine_decay_linear_warmup
+    from mvp import functional as MF
+
+    cfg = config.compose("snorm_training", argv)
+    rank, local, world = mdist.env_setup("nccl")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ds = cfg["dataset"]
+    hw, nb, B = tuple(ds["image_size"]), ds["num_batches"], cfg["batch_size"]
+    model = config.instantiate(cfg["backbone"]).to(dev)
+    probe = config.instantiate(cfg["probe"], feat_dim=model.feat_dim).to(dev)
+    opt = FlatAdamW([{"params": probe.parameters(), "lr": cfg["optimizer"]["probe_lr"]}])
+    n_ep = cfg["optimizer"]["n_epochs"]
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, n_ep * nb, cfg["optimizer"]["warmup_epochs"] * nb))
+    for ep in range(n_ep):
+        tot = 0.0
+        for batch in batches(nb, B, hw, rank):
+            images, target = batch["image"].to(dev), batch["snorm"].to(dev)
+            mask = batch["depth"].to(dev) > 0                       # train_snorm.py:95
+            tot += train_snorm_step(model, probe, opt, sched, images, target, mask).item()
+        if rank == 0:
+            print(f"epoch {ep} train loss {tot / nb:.4f}")
+    if rank == 0:
+        model.eval(); probe.eval()
+        b = next(batches(1, B, hw, 99))
+        with torch.no_grad():
+            pred = MF.interpolate(probe(model(b["image"].to(dev))).contiguous(), size=hw, mode="bicubic")
+        gm, _, _ = evaluate_surface_norm(pred, b["snorm"].to(dev), None, image_average=True, is_navi=True)
+        print("valid " + " ".join(f"{k} {float(v):.4f}" for k, v in gm.items()))
+        out = os.path.join(cfg["output_dir"], "snorm_exps", f"{model.checkpoint_name}_{probe.name}".replace("$", ""))
+        print("saved", checkpoint.save_checkpoint(os.path.join(out, "ckpt.pth"), cfg, model, probe))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
