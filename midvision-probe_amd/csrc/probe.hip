@@ -85,11 +85,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const mvp_colsum_ar
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(const mvp_colsum_args p, const float* part, int nchunk) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= p.N) return;
-  float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * p.N + c];
-  p.out[c] = p.accumulate ? p.out[c] + s : s;
+  // 64 columns x 4 chunk groups per workgroup: the chunk loads of a thread are independent (4 accumulators), the
+  // combination order is fixed -> deterministic.
+  __shared__ float red[4][64];
+  const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < p.N) {
+    int k = rg;
+    for (; k + 12 < nchunk; k += 16) {
+      s0 += part[(size_t)k * p.N + c];
+      s1 += part[(size_t)(k + 4) * p.N + c];
+      s2 += part[(size_t)(k + 8) * p.N + c];
+      s3 += part[(size_t)(k + 12) * p.N + c];
+    }
+    for (; k < nchunk; k += 4) s0 += part[(size_t)k * p.N + c];
+  }
+  red[rg][lc] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < p.N) {
+    const float s = (red[0][lc] + red[1][lc]) + (red[2][lc] + red[3][lc]);
+    p.out[c] = p.accumulate ? p.out[c] + s : s;
+  }
 }
 
 inline int grid_for(int64_t work) {
@@ -137,7 +154,7 @@ extern "C" int mvp_colsum(const mvp_colsum_args* a, void* stream) {
   const int nchunk = (a->M + CS_CHUNK - 1) / CS_CHUNK;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((a->N + 63) / 64, nchunk), dim3(256), 0, s, *a, (float*)a->workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((a->N + 255) / 256), dim3(256), 0, s, *a, (const float*)a->workspace, nchunk);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((a->N + 63) / 64), dim3(256), 0, s, *a, (const float*)a->workspace, nchunk);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

@@ -82,62 +82,72 @@ constexpr int BN_RB = 8;   // rows per partial-statistics slab (small slabs -> ~
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int C) {
   const int r0 = blockIdx.x * BN_RB;
   const int nr = min(BN_RB, M - r0);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float* col = x + (size_t)r0 * C + c;
-    const float shift = col[0];
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < nr; ++r) {
-      const float d = col[(size_t)r * C] - shift;
-      s1 += d;
-      s2 += d * d;
-    }
-    float* o = part + ((size_t)blockIdx.x * C + c) * 3;
-    o[0] = shift; o[1] = s1; o[2] = s2;
-  }
-}
-
-// Pass 2: one wave per channel.  Each lane folds its slabs (stride 64) with Chan's update in
-// fp64, then the 64 lane-partials are combined by an xor-shuffle tree (fixed order ->
-// deterministic) -> mean, biased var; running stats (momentum, unbiased var) and the affine
-// scale/shift used by the apply pass.
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, m, 64);
-  hi = __shfl_xor(hi, m, 64);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
-                                                          float* __restrict__ ss, int M, int nslab) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= p.C) return;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int s = lane; s < nslab; s += 64) {
-    const float* o = part + ((size_t)s * p.C + c) * 3;
-    const double nb = (double)min(BN_RB, M - s * BN_RB);
-    const double mb = (double)o[0] + (double)o[1] / nb;
-    const double m2b = (double)o[2] - (double)o[1] * (double)o[1] / nb;
-    const double delta = mb - mean;
-    const double nn = n + nb;
-    mean += delta * nb / nn;
-    m2 += m2b + delta * delta * n * nb / nn;
-    n = nn;
-  }
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* col = x + (size_t)r0 * C + c;
+  float v[BN_RB];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double n2 = shfl_xor_f64(n, o), mean2 = shfl_xor_f64(mean, o), m22 = shfl_xor_f64(m2, o);
-    const double nn = n + n2;
-    if (nn > 0.0) {
-      const double delta = mean2 - mean;
-      // symmetric form so that both partners compute the identical combined triple
-      const double cm = (n * mean + n2 * mean2) / nn;
-      m2 = m2 + m22 + delta * delta * n * n2 / nn;
-      mean = cm;
-    }
-    n = nn;
+  for (int r = 0; r < BN_RB; ++r) v[r] = col[(size_t)min(r, nr - 1) * C];  // all loads in flight together
+  const float shift = v[0];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < BN_RB; ++r) {
+    const float d = (r < nr) ? v[r] - shift : 0.f;
+    s1 += d;
+    s2 += d * d;
   }
-  if (lane != 0) return;
+  float* o = part + ((size_t)blockIdx.x * C + c) * 3;
+  o[0] = shift; o[1] = s1; o[2] = s2;
+}
+
+// Pass 2: a workgroup = 64 channels x 16 slab groups (coalesced 768-B reads of the [slab][channel][3] partials).
+// Each thread folds its slabs (stride 16) into fp64 moments about the channel's first-slab shift (no per-slab
+// division; fp64 keeps the centred second moment exact to ~1e-13 relative), the 16 groups are combined through LDS
+// in a fixed order (deterministic) -> mean, biased var; running stats (momentum, unbiased var) and the affine
+// scale/shift used by the apply pass.
+constexpr int BN_FG = 16;
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
+                                                           float* __restrict__ ss, int M, int nslab) {
+  __shared__ double red[BN_FG][64][2];
+  const int lc = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
+  const bool ok = c < p.C;
+  const double ref = ok ? (double)part[(size_t)c * 3] : 0.0;  // slab 0's shift: common origin of the moments
+  double s1 = 0.0, s2 = 0.0;
+  if (ok) {
+    for (int s0 = grp; s0 < nslab; s0 += BN_FG * 8) {
+      float o0[8], o1[8], o2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // 24 independent loads in flight
+        const int s = min(s0 + u * BN_FG, nslab - 1);
+        const float* o = part + ((size_t)s * p.C + c) * 3;
+        o0[u] = o[0]; o1[u] = o[1]; o2[u] = o[2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * BN_FG;
+        if (s < nslab) {
+          const double nb = (double)min(BN_RB, M - s * BN_RB);
+          const double d = (double)o0[u] - ref, a1 = (double)o1[u], a2 = (double)o2[u];
+          // sum (x - ref) and sum (x - ref)^2 of this slab from its own shifted sums
+          s1 += a1 + nb * d;
+          s2 += a2 + 2.0 * d * a1 + nb * d * d;
+        }
+      }
+    }
+  }
+  red[grp][lc][0] = s1;
+  red[grp][lc][1] = s2;
+  __syncthreads();
+  if (grp != 0 || !ok) return;
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int g = 0; g < BN_FG; ++g) { s1 += red[g][lc][0]; s2 += red[g][lc][1]; }
+  const double n = (double)M;
+  const double dm = s1 / n;
+  const double mean = ref + dm;
+  const double m2 = fmax(s2 - s1 * dm, 0.0);
   const double var = m2 / n;
   p.stats[c] = (float)mean;
   p.stats[p.C + c] = (float)var;
@@ -304,8 +314,8 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   float* part = (float*)a->workspace;
   float* ss = part + (size_t)nslab * a->C * 3;
   if (a->mode == 0) {
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, a->x, part, M, a->C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 3) / 4), dim3(256), 0, s, *a, part, ss, M, nslab);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab, (a->C + 255) / 256), dim3(256), 0, s, a->x, part, M, a->C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 63) / 64), dim3(1024), 0, s, *a, part, ss, M, nslab);
   } else {
     hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
   }

@@ -212,8 +212,7 @@ class ViTBackbone(nn.Module):
         with torch.no_grad():
             taps = eng.forward_taps(images, self.multilayers, bn=bns, bn_mode=mode, tap_input_of_block=self.tap_input_of_block)
             if self.add_norm and self.training:
-                for bn in self.batchnorms:
-                    bn.num_batches_tracked += 1
+                torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms], 1)  # one launch for all taps
         return taps
 
     def _finish(self, taps: TapOutputs):

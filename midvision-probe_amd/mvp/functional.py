@@ -78,9 +78,26 @@ def pack_features(feats: Sequence[torch.Tensor], precision: int) -> PackedFeatur
     off = 0
     for f in feats:
         C = int(f.shape[1])
-        ops.pack_nchw_tokens(f.contiguous().float(), B, C, h * w, tok=pack.tok, ld_tok=pack.Cpad, col_off=off, tokT=pack.tokT, ldT=pack.Mpad)
+        ops.pack_nchw_tokens(f.contiguous().float(), B, C, h * w, tok=pack.tok, ld_tok=pack.Cpad, col_off=off)
         off += C
     return pack
+
+
+def _head_weight_grad(gl0: torch.Tensor, K: int, pack: PackedFeatures, pr: int) -> torch.Tensor:
+    """dW[K, Ctot] = gl0ᵀ · F over the token axis: TN split-K kernel on the row-major gradient and the packed features
+    (the weight gradient of the 1x1 conv, probes.py:431)."""
+    from . import conv
+    dev = gl0.device
+    Kg = (K + 127) // 128 * 128
+    if Kg != K:  # the TN tile is 128 output channels wide: zero pad columns
+        gpad = gl0.new_zeros(pack.M, Kg)
+        gpad[:, :K] = gl0
+        gl0 = gpad
+    gp = ops.split_bf16(gl0, pr)
+    dW = torch.empty(K, pack.Cpad, dtype=torch.float32, device=dev)
+    geo = dict(B=pack.B, H=pack.h, W=pack.w, C=pack.Cpad, Ho=pack.h, Wo=pack.w, kh=1, kw=1, stride=1, pad=0, up=0)
+    conv.conv_dw(gp, Kg, pack.tok, pack.Cpad, geo, K, dW, precision=pr)
+    return dW[:, :pack.Ctot]
 
 
 class _LinearHeadK1(torch.autograd.Function):
@@ -121,13 +138,7 @@ class _LinearHeadK1(torch.autograd.Function):
         glq = glq.contiguous()
         gl0 = torch.empty(pack.M, K4, dtype=torch.float32, device=dev)
         ops.resize(glq, gl0, B, h, w, 4 * h, 4 * w, lib.RESIZE_BILINEAR, channels_last=True, Cdim=K4, scale_h=4.0, scale_w=4.0, backward=True)
-        # dW[K, Ctot] = gl0ᵀ · F : both operands K-major over the (zero padded) token axis
-        gT = pack.scratch.get(("gT", K4))
-        if gT is None:  # pad columns [M, Mpad) are zeroed once and never written
-            gT = pack.scratch[("gT", K4)] = ops.zeros_pair((K4, pack.Mpad), pr, dev)
-        ops.pack_nchw_tokens(gl0, 1, pack.M, K4, tok=gT, ld_tok=pack.Mpad, col_off=0)
-        dW = torch.empty(K4, Ctot, dtype=torch.float32, device=dev)
-        ops.gemm(gT, pack.tokT, K4, Ctot, pack.Mpad, out_f32=dW, precision=pr)
+        dW = _head_weight_grad(gl0, K4, pack, pr)
         db = torch.empty(K4, dtype=torch.float32, device=dev)
         ops.colsum(gl0, db, pack.M, K4)
         return dW[:K].reshape(ctx.wshape), db[:K], None, None
@@ -181,12 +192,7 @@ class _LinearBinsHead(torch.autograd.Function):
         gl0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
         a = lib.LinearBinsArgs(None, lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), lib.ptr(gd.contiguous().float()), lib.ptr(gl0), B, h, w, K, 4, mn, mx)
         lib.call("mvp_linear_bins_bwd", a)
-        gT = pack.scratch.get(("gT", K))
-        if gT is None:
-            gT = pack.scratch[("gT", K)] = ops.zeros_pair((K, pack.Mpad), pr, dev)
-        ops.pack_nchw_tokens(gl0, 1, pack.M, K, tok=gT, ld_tok=pack.Mpad, col_off=0)
-        dW = torch.empty(K, Ctot, dtype=torch.float32, device=dev)
-        ops.gemm(gT, pack.tokT, K, Ctot, pack.Mpad, out_f32=dW, precision=pr)
+        dW = _head_weight_grad(gl0, K, pack, pr)
         db = torch.empty(K, dtype=torch.float32, device=dev)
         ops.colsum(gl0, db, pack.M, K)
         return dW.reshape(ctx.wshape), db, None, None, None, None, None

@@ -122,8 +122,7 @@ class ResNetBackbone(nn.Module):
                 mode = 0 if self.training else 1
             outs = self.engine().forward_taps(x, self.multilayers, bn=bns, bn_mode=mode)
             if self.add_norm and self.training:
-                for i in self.multilayers:
-                    self.batchnorms[i].num_batches_tracked += 1
+                torch._foreach_add_([self.batchnorms[i].num_batches_tracked for i in self.multilayers], 1)
         return outs[0] if len(outs) == 1 else outs
 
 

@@ -42,15 +42,15 @@ class TapOutputs(list):
 
 
 class PackedFeatures:
-    """Token-major operand of the linear-probe GEMMs: F [Mpad, Ctot] and Fᵀ [Ctot, Mpad] bf16 pairs."""
+    """Token-major operand of the linear-probe GEMMs: F [Mpad, Cpad] bf16 pair (forward: F·Wᵀ by the NT GEMM;
+    weight gradient: gᵀ·F by the TN split-K kernel, which reads the same row-major image through transposed LDS reads)."""
 
     def __init__(self, B, h, w, Ctot, precision, device):
         self.B, self.h, self.w, self.Ctot, self.precision = B, h, w, Ctot, precision
         self.M = B * h * w
         self.Mpad = (self.M + 63) // 64 * 64
-        self.Cpad = (Ctot + 63) // 64 * 64  # GEMM K dims are multiples of 64; pad columns stay zero
+        self.Cpad = (Ctot + 127) // 128 * 128  # NT GEMM K % 64, TN kernel Cin % 128; pad columns stay zero
         self.tok = ops.zeros_pair((self.Mpad, self.Cpad), precision, device)
-        self.tokT = ops.zeros_pair((Ctot, self.Mpad), precision, device)
         self.sources: List[Tuple[int, int]] = []  # (data_ptr, _version) of the NCHW maps packed here
         self.generation = 0  # bumped every time the buffers are rewritten (they are reused across steps)
         self.scratch: Dict[str, object] = {}  # per-shape scratch of the head backward (zero-padded once)
@@ -230,7 +230,7 @@ class ViTEngine:
                 gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                 running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                 nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
-                tokT=packed.tokT if packed else None, ldT=packed.Mpad if packed else 0, mode=bn_mode)
+                mode=bn_mode)
             outs.append(nchw)
 
         last = max(layers)
