@@ -121,8 +121,16 @@ typedef struct {
   const uint8_t* relu_mask; uint8_t* out_mask; int ldm; int mask_mode;
   const float* residual2; /* optional second fp32 addend, same row stride ldr (fusion-block "+ skip") */
   int act_after_res;      /* 1: apply MVP_ACT_RELU after the residual adds (ResNet bottleneck)          */
+  /* --- split-K (splitk > 1, plain linear GEMMs only: ignored with conv / mask / residual2 / act_after_res):
+   * the K range is cut into `splitk` parts that run as separate workgroups; the last part to finish sums
+   * the fp32 partial tiles in a fixed order (bit-reproducible) and runs the fused epilogue.  For GEMMs
+   * with too few output tiles to fill 256 CUs (N = 768 projections, the probe head at M ~ 3k rows).
+   * splitk_ws: >= mvp_gemm_splitk_workspace_bytes(M, N, splitk) bytes whose leading tile counters are ZERO
+   * at first use (they reset themselves); not shared by GEMMs running concurrently on other streams.   */
+  int splitk; void* splitk_ws; int64_t splitk_ws_bytes;
 } mvp_gemm_args;
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
+int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm forward: fp32 rows [M, C] -> bf16 pair [M, C] (the next GEMM's A operand).

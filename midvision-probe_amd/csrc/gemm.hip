@@ -33,6 +33,10 @@
 
 namespace {
 
+// split-K workspace = [tile counters: fixed 64 KiB region][fp32 partial tiles]; the fixed counter region keeps the
+// counters of GEMMs of different shapes that share one workspace apart from each other's partials.
+constexpr int SPLITK_CTR_BYTES = 65536;
+
 // Branch-free erf GELU: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one
 // v_rcp.  (ocml erff measured ~17 us of VALU on the fc1 epilogue.)
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -50,8 +54,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // (ky*kw + kx)*C + c, output row m = (b, y, x) on the Ho x Wo grid.  A K-tile never straddles
 // a tap (C % BK == 0), so per tile every staged row is ONE 16-byte-aligned run of channels of
 // one source pixel — or of the caller's zero page when the tap falls into the padding.
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT>
+//
+// KSPLIT: split-K for GEMMs whose tile count cannot fill 256 CUs (N = 768 projections at M ~ 3k rows: 300 tiles,
+// so 44 CUs carry two tiles and set the time).  The grid is tiles x S units; a unit accumulates K-range `split` of
+// its tile, stores the raw accumulators to the workspace and bumps the tile's counter; the unit that arrives LAST
+// (no unit ever waits) sums all S partials in the fixed order 0..S-1 (deterministic whichever unit does it) and
+// runs the normal fused epilogue.  The counter resets itself for the next launch.
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT, bool KSPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
+  static_assert(!(KSPLIT && (CONV || EXT)), "split-K is compiled for the plain linear GEMMs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int ROWB = BK * 2;            // bytes per LDS row
@@ -66,14 +77,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int unit = xcd_remap(blockIdx.x, gridDim.x);  // units of one tile are neighbours -> same XCD / L2
+  const int S = KSPLIT ? p.splitk : 1;
+  const int bid = KSPLIT ? unit / S : unit;
+  const int split = KSPLIT ? unit - bid * S : 0;
   const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int nk_all = p.K / BK;
+  const int kt0 = KSPLIT ? (int)(((long)split * nk_all) / S) : 0;
 #if MVP_ABLATE == 4
   const int nk = 0;
 #else
-  const int nk = p.K / BK;
+  const int nk = KSPLIT ? (int)(((long)(split + 1) * nk_all) / S) - kt0 : nk_all;
 #endif
 
   const int rsub = lane / CH;  // row inside an LDS-DMA piece
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
 
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
-    const int k0 = kt * BK;
+    const int k0 = (kt0 + kt) * BK;
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
       const int r = ps * 4 * RPP + wave * RPP;
@@ -212,6 +228,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();  // every wave is done with the staging buffers -> reuse them for the epilogue
+
+  if (KSPLIT && S > 1) {
+    // Cross-workgroup hand-over WITHOUT device-scope fences (a __threadfence() here writes back / invalidates the
+    // XCD's L2 once per workgroup: measured 3x slower GEMMs).  Every access to the shared bytes carries the scope
+    // itself: partials leave with 16-byte `sc1` (write-through) stores that the storing wave waits for (vmcnt(0))
+    // before the workgroup's ONE agent-scope atomic add; the workgroup whose add returned S-1 came last and reads
+    // all partials back with `sc1` loads after a workgroup barrier (MI355X_MICROARCH.md, hand-off table).
+    int* ctr = (int*)p.splitk_ws;
+    constexpr int NACC = NT * MT;
+    constexpr int UNIT_BYTES = NACC * 256 * 16;  // [acc register][thread] float4: 1-KiB wave accesses
+    char* part = (char*)p.splitk_ws + SPLITK_CTR_BYTES;
+    constexpr int AUX_SC1 = 16;  // gfx940+ cache policy bit 4
+    {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part + (size_t)unit * UNIT_BYTES, 0, UNIT_BYTES, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, ((i * MT + j) * 256 + tid) * 16, 0, AUX_SC1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(ctr + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    for (int sp = 0; sp < S; ++sp) {  // fixed order 0..S-1 whichever unit reduces -> bit-reproducible
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part + ((size_t)bid * S + sp) * UNIT_BYTES, 0, UNIT_BYTES, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const f32x4_t t = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((i * MT + j) * 256 + tid) * 16, 0, AUX_SC1));
+          acc[i][j] = (sp == 0) ? t : acc[i][j] + t;
+        }
+    }
+    if (tid == 0) __hip_atomic_store(ctr + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
 
   // ---------------------------------------------------------------- epilogue through LDS
   // EXT = false compiles the ReLU-gate / second-residual / post-residual-ReLU features out of the
@@ -362,7 +416,37 @@ int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
   return MVP_OK;
 }
 
+template <int BM, int BN>
+int64_t splitk_ws_bytes(int M, int N, int S) {
+  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  return SPLITK_CTR_BYTES + tiles * S * (int64_t)(BM * BN * 4);
+}
+
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
+int launch_gemm_splitk(const mvp_gemm_args* a, hipStream_t s) {
+  constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE>();
+  static int configured = [] {
+    return (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, false, false, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  }();
+  if (configured != 0) return MVP_ELAUNCH;
+  if (!a->splitk_ws || a->splitk_ws_bytes < splitk_ws_bytes<BM, BN>(a->M, a->N, a->splitk)) return MVP_EINVAL;
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  if (tiles > SPLITK_CTR_BYTES / 4) return MVP_EINVAL;
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, false, false, true>), dim3(tiles * a->splitk), dim3(256), SMEM, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+// One tile rule for the split-K path (the workspace query must agree with the launch).
+inline bool splitk_wide(int N) { return N >= 1024; }
+
 }  // namespace
+
+extern "C" int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits) {
+  if (M <= 0 || N <= 0 || splits < 1) return 0;
+  return splitk_wide(N) ? splitk_ws_bytes<128, 128>(M, N, splits) : splitk_ws_bytes<128, 64>(M, N, splits);
+}
 
 // Diagnostic override (tools/gemm_bench.py): -DMVP_F_BM=.. -DMVP_F_BN=.. -DMVP_F_BK=.. -DMVP_F_ST=..
 extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
@@ -381,6 +465,12 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     // BK = 32 keeps every tile inside one tap for any C % 32 == 0 and gives 2-3 workgroups per CU
     if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
     return x3 ? launch_gemm<128, 64, 32, 3, 2, true>(a, s) : launch_gemm<128, 64, 32, 1, 2, true>(a, s);
+  }
+  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res;
+  if (a->splitk > 1 && !ext) {  // (with the ReLU-gate / second-residual epilogues the request is ignored)
+    if (a->splitk > 64 || a->K / 64 < a->splitk) return MVP_EINVAL;
+    if (splitk_wide(a->N)) return x3 ? launch_gemm_splitk<128, 128, 32, 3, 2>(a, s) : launch_gemm_splitk<128, 128, 64, 1, 2>(a, s);
+    return x3 ? launch_gemm_splitk<128, 64, 32, 3, 2>(a, s) : launch_gemm_splitk<128, 64, 64, 1, 2>(a, s);
   }
 #ifdef MVP_F_BM
   return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST>(a, s) : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST>(a, s);

@@ -50,7 +50,7 @@ class GemmArgs(C.Structure):
                 ("row_group", _i), ("row_group_stride", _i), ("row_group_off", _i), ("res_row_mod", _i),
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
-                ("residual2", _vp), ("act_after_res", _i)]
+                ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64)]
 
 
 class LayerNormArgs(C.Structure):
@@ -167,6 +167,7 @@ SYMBOLS = {
     "mvp_split_bf16": SplitArgs,
     "mvp_patch_gather": PatchGatherArgs,
     "mvp_gemm_bias_act_res": GemmArgs,
+    "mvp_gemm_splitk_workspace_bytes": None,
     "mvp_layernorm_fwd": LayerNormArgs,
     "mvp_attention_fwd": AttentionArgs,
     "mvp_cls_rows": ClsRowsArgs,
@@ -227,6 +228,8 @@ def load() -> C.CDLL:
     lib.mvp_colsum_workspace_bytes.restype = _i64
     lib.mvp_metrics_workspace_bytes.argtypes = [_i]
     lib.mvp_metrics_workspace_bytes.restype = _i64
+    lib.mvp_gemm_splitk_workspace_bytes.argtypes = [_i, _i, _i]
+    lib.mvp_gemm_splitk_workspace_bytes.restype = _i64
     lib.mvp_gemm_tn_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]
     lib.mvp_gemm_tn_workspace_bytes.restype = _i64
     lib.mvp_depth_loss_workspace_bytes.argtypes = [_i, _i64]

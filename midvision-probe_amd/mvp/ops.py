@@ -25,8 +25,11 @@ def set_trace(lst) -> None:
     _TRACE = lst
 
 
-def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3) -> str:
+def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: int = 1) -> str:
     """Mirror of the tile choice in csrc/gemm.hip -> template arguments BM,BN,BK,SPLIT,NSTAGE."""
+    if splitk > 1:
+        bn = 128 if N >= 1024 else 64
+        return f"128, {bn}, 32, 3, 2, splitk" if precision == PREC_BF16X3 else f"128, {bn}, 64, 1, 2, splitk"
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     if precision == PREC_BF16X3:
         if t128 >= 400:
@@ -70,10 +73,31 @@ def patch_gather(images: torch.Tensor, out: Pair, P: int, gh: int, gw: int, pad_
     lib.call("mvp_patch_gather", a)
 
 
+_SPLITK_WS = {}  # device -> zero-initialised workspace (tile counters reset themselves; one stream at a time)
+
+
+def splitk_auto(M: int, N: int, K: int) -> int:
+    """Split-K factor used when the caller does not give one: always 1.  Measured on MI355X (tools/splitk_bench.py,
+    B=16 hot-path shapes, bf16x3): proj 27.1 us unsplit vs 33.6 (S=2); fc2 71.8 vs 77.3 (S=2) / 86.0 (S=4);
+    head 34.7 vs 33.2 (S=4, within noise).  The N=768 GEMMs are bound by the L2->LDS load path of the bf16-pair
+    operands, not by tile imbalance, so extra workgroups only add the partial-tile round trip.  The kernel path
+    stays available (splitk=S) for shapes with far fewer tiles than CUs."""
+    return 1
+
+
+def _splitk_workspace(M: int, N: int, S: int, device) -> torch.Tensor:
+    need = int(lib.load().mvp_gemm_splitk_workspace_bytes(M, N, S))
+    ws = _SPLITK_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = _SPLITK_WS[device] = torch.zeros(max(need, 32 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, out_f32=None, out: Optional[Pair] = None,
          act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
-         row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0) -> None:
-    """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res)."""
+         row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0,
+         splitk: Optional[int] = None) -> None:
+    """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off."""
     o_hi, o_lo = out if out is not None else (None, None)
     args = lib.GemmArgs(
         lib.ptr(a[0]), lib.ptr(a[1]), lib.ptr(w[0]), lib.ptr(w[1]), lib.ptr(bias), lib.ptr(residual),
@@ -84,6 +108,12 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     args.act_after_res = int(act_after_res)
     if out_mask is not None:
         args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
+    S = 1
+    if out_mask is None and not act_after_res:
+        S = splitk_auto(M, N, K) if splitk is None else int(splitk)
+    if S > 1:
+        ws = _splitk_workspace(M, N, S, a[0].device)
+        args.splitk, args.splitk_ws, args.splitk_ws_bytes = S, lib.ptr(ws), ws.numel()
     if _TRACE is None:
         lib.call("mvp_gemm_bias_act_res", args)
         return
@@ -91,7 +121,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     e0.record()
     lib.call("mvp_gemm_bias_act_res", args)
     e1.record()
-    _TRACE.append(("gemm", gemm_tile(M, N, K, precision), precision, 2.0 * M * N * K, e0, e1))
+    _TRACE.append(("gemm", gemm_tile(M, N, K, precision, S), precision, 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,

@@ -67,6 +67,46 @@ def test_gemm_epilogues(dev, precision, shape):
         assert rel_l2(pair.cpu().numpy(), ref.numpy()) < tol + 2e-5
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_gemm_splitk(dev, precision):
+    """Split-K (last-arriving workgroup reduces in a fixed order): parity with fp64 for several split factors and
+    both tile widths, bit-reproducible across launches, and shapes alternating on ONE workspace (the tile
+    counters must return to zero after every launch)."""
+    from mvp import lib, ops
+    from mvp.vit import parse_precision
+
+    pr = parse_precision(precision)
+    tol = 2e-5 if pr == lib.PREC_BF16 else 5e-5
+    cases = []
+    for (M, N, K) in ((3152, 768, 3072), (3136, 256, 3072), (777, 1280, 1024), (130, 72, 768)):
+        g = torch.Generator().manual_seed(M + N + K)
+        a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+        bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ap, wp = ops.split_bf16(a.to(dev), pr), ops.split_bf16(w.to(dev), pr)
+        if pr == lib.PREC_BF16:
+            a, w = _bf16_round(a), _bf16_round(w)
+        ref = F.gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+        cases.append((M, N, K, ap, wp, bias.to(dev), res.to(dev), ref.numpy()))
+    for S in (2, 3, 5, 8):
+        outs = []
+        for rep in range(2):
+            for (M, N, K, ap, wp, bias, res, ref) in cases:  # alternate shapes on the shared workspace
+                out = torch.full((M, N), float("nan"), device=dev)
+                op = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+                ops.gemm(ap, wp, M, N, K, bias=bias, residual=res, out_f32=out, out=op, act=lib.ACT_GELU, precision=pr, splitk=S)
+                torch.cuda.synchronize()
+                assert rel_l2(out.cpu().numpy(), ref) < tol, (M, N, K, S)
+                assert rel_l2((op[0].float() + op[1].float()).cpu().numpy(), ref) < tol + 2e-5
+                outs.append(out)
+        n = len(cases)
+        for i in range(n):
+            assert torch.equal(outs[i], outs[n + i]), "split-K result must be bit-reproducible"
+    # invalid: more parts than 64-wide K chunks
+    with pytest.raises(lib.MvpError):
+        M, N, K, ap, wp, bias, res, ref = cases[3]
+        ops.gemm(ap, wp, M, N, K, out_f32=torch.empty(M, N, device=dev), precision=pr, splitk=16)
+
+
 def test_gemm_row_remap(dev):
     """Patch-embed form: rows written behind a CLS slot, pos-embed residual indexed mod hw."""
     from mvp import lib, ops
