@@ -175,21 +175,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
     if (s0 < nk) stage(s0, s0);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + NSTAGE - 2 < nk) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#if MVP_ABLATE != 2
-    if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
-#endif
-#if MVP_ABLATE == 3
-    continue;
-#endif
-    const char* base = smem + (kt % NSTAGE) * STAGE;
+  auto mma_tile = [&](const char* base) {
     const char* ab = base + (wm0 + frow) * ROWB;
     const char* wb = base + A_BYTES * NARR + (wn0 + frow) * ROWB;
 #pragma unroll
@@ -225,6 +211,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_hi[j], acc[i][j], 0, 0, 0);
         }
     }
+    };
+
+  if constexpr (NSTAGE == 1) {
+    // Single LDS buffer (BK = 64: whole 128-byte lines per LDS-DMA row -> half the L2 requests of BK = 32): no
+    // intra-workgroup prefetch; the 2-3 co-resident workgroups of a CU overlap each other's load and MFMA phases.
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everybody finished reading the buffer
+      }
+      stage(0, kt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      mma_tile(smem);
+    }
+  } else {
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NSTAGE - 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#if MVP_ABLATE != 2
+    if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kt + NSTAGE - 1);
+#endif
+#if MVP_ABLATE == 3
+    continue;
+#endif
+    mma_tile(smem + (kt % NSTAGE) * STAGE);
+  }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();  // every wave is done with the staging buffers -> reuse them for the epilogue
@@ -475,16 +493,29 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
 #ifdef MVP_F_BM
   return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST>(a, s) : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST>(a, s);
 #else
-  // Tile choice (measured on MI355X at the hot-path shapes, tools/gemm_bench.py; M = B*N ~ 3k rows):
-  // the grid, not the MFMA pipe, is the first limiter, and resident workgroups per CU matter
-  // more than pipeline depth (a third stage that costs residency loses), so: 2 stages, BK = 32
-  // for the split mode (48-64 KB LDS -> 2-3 workgroups/CU), 128x128 only when that still gives
-  // >= ~1.5 waves of tiles, long-K skinny-N (the probe head) on BK = 64.
+  // Tile choice, split mode (measured on MI355X, tools/gemm_bench.py --tiles at M = 3152 and M = 12608; us, old -> new):
+  //   qkv 41.3 -> 37.2 / 150.8 -> 138.6, proj 21.1 -> 17.2 / 63.7 -> 49.5, fc1 62.7 -> 51.3 / 193.8 -> 180.6,
+  //   fc2 67.3 -> 59.1 / 208.6 -> 173.4.
+  // What the counters said (profiles/r01_pmc_*): the bf16-pair GEMMs sit at the L2 REQUEST rate (TCC_REQ x 64 B =
+  // 8.4 TB/s = half the 128-B-line ceiling) with BK = 32, whose LDS-DMA rows are half lines.  BK = 64 fetches whole
+  // lines; keeping ONE LDS stage (no intra-workgroup prefetch) keeps 2-5 workgroups resident per CU, and those
+  // overlap each other's load and MFMA phases better than a second stage would (two stages at BK = 64 cost the
+  // residency and measured slower everywhere except the few-tile probe head).
   const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
   if (x3) {
-    if (t128 >= 400) return launch_gemm<128, 128, 32, 3, 2>(a, s);
-    if (a->N <= 256 && a->K >= 2048) return launch_gemm<64, 64, 64, 3, 2>(a, s);
-    return launch_gemm<128, 64, 32, 3, 2>(a, s);
+    if (a->N <= 256 && a->K >= 2048) {  // probe head: few tiles, long K
+      if (a->M >= 8192) return launch_gemm<128, 64, 64, 3, 1>(a, s);
+      return launch_gemm<64, 64, 64, 3, 2>(a, s);
+    }
+    if (a->N >= 1024) {
+      // one round of 128x128 tiles (2 resident per CU = 512 slots) or many rounds: big tiles; in between the
+      // second, mostly empty round costs more than the smaller tile's extra operand traffic
+      if (t128 <= 512 || t128 >= 1536) return launch_gemm<128, 128, 64, 3, 1>(a, s);
+      return launch_gemm<64, 128, 64, 3, 1>(a, s);
+    }
+    const long t64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64);
+    if (t64 <= 1280) return launch_gemm<64, 64, 64, 3, 1>(a, s);  // 5 resident per CU
+    return launch_gemm<128, 64, 64, 3, 1>(a, s);
   }
   if (t128 >= 400) return launch_gemm<128, 128, 64, 1, 2>(a, s);
   return launch_gemm<64, 64, 64, 1, 2>(a, s);
