@@ -480,7 +480,12 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     if (!a->zero_page || a->cC <= 0 || (a->cC & 31) || a->ckh <= 0 || a->ckw <= 0 || a->cstride <= 0) return MVP_EINVAL;
     if (a->K != a->ckh * a->ckw * a->cC || a->cHo <= 0 || a->cWo <= 0 || (a->M % (a->cHo * a->cWo))) return MVP_EINVAL;
     if ((a->cH & ((1 << a->cup) - 1)) || (a->cW & ((1 << a->cup) - 1))) return MVP_EINVAL;
-    // BK = 32 keeps every tile inside one tap for any C % 32 == 0 and gives 2-3 workgroups per CU
+    // A K-tile must stay inside one tap: BK = 64 (whole-line rows, single stage: see the tile notes below) when
+    // C % 64 == 0, else BK = 32 (any C % 32 == 0), two stages.
+    if (x3 && (a->cC & 63) == 0) {
+      if (a->N > 64) return launch_gemm<128, 128, 64, 3, 1, true>(a, s);
+      return launch_gemm<128, 64, 64, 3, 1, true>(a, s);
+    }
     if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
     return x3 ? launch_gemm<128, 64, 32, 3, 2, true>(a, s) : launch_gemm<128, 64, 32, 1, 2, true>(a, s);
   }
