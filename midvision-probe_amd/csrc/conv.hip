@@ -8,6 +8,7 @@
 //                      through ds_read_b64_tr_b16; split-K over pixel ranges into fp32 partial slabs
 //   splitk_reduce      sum of the slabs (fixed order) -> torch-layout gradient (optionally +=)
 #include "mvp_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void maxpool_cl_kernel(const mvp_maxpool_cl_ar
 // MFMA roles: A operand = X fragment (rows = input channel j), B operand = G fragment
 // (cols = output channel i): each lane then owns 4 consecutive j of one i -> 16-byte stores
 // into dW's [i][tap][j] rows.
-template <int SPLIT>
+template <int SPLIT, int NST>
 __global__ __launch_bounds__(256) void gemm_tn_conv_kernel(const mvp_gemm_tn_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
@@ -225,13 +226,7 @@ __global__ __launch_bounds__(256) void gemm_tn_conv_kernel(const mvp_gemm_tn_arg
     return row * 256 + ((c32 ^ fsw(row)) << 5) + ((pp >> 1) << 4) + ((pp & 1) << 3);
   };
 
-  if (nk > 0) stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* gb = smem + (kt & 1) * STAGE;
+  auto mma_tile = [&](const char* gb) {
     const char* xb = gb + NARR * TILE;
     const int r0 = g4 * 8 + q;
     bf16x8_t xf_hi[4], xf_lo[4], gf_hi[4], gf_lo[4];
@@ -270,6 +265,28 @@ __global__ __launch_bounds__(256) void gemm_tn_conv_kernel(const mvp_gemm_tn_arg
         }
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf_hi[a], gf_hi[b], acc[a][b], 0, 0, 0);
       }
+  };
+  if (NST == 1) {
+    // one LDS stage (32 KB): up to 4-5 workgroups resident per CU overlap each other's load and MFMA phases
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      stage(0, kt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      mma_tile(smem);
+    }
+  } else {
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      mma_tile(smem + (kt & 1) * STAGE);
+    }
   }
 
   // partial slab [split][Cout][T*Cin]: lane owns i = col (lane & 15), 4 consecutive j (rows 4*g4 ..)
@@ -307,16 +324,16 @@ inline int grid_for(int64_t work, int cap = 4096) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <int SPLIT>
+template <int SPLIT, int NST>
 int launch_tn(const mvp_gemm_tn_args* a, hipStream_t s) {
-  constexpr int SMEM = 2 * 2 * ((SPLIT == 3) ? 2 : 1) * 32 * 256;
+  constexpr int SMEM = NST * 2 * ((SPLIT == 3) ? 2 : 1) * 32 * 256;
   static int configured = [] {
-    return (int)hipFuncSetAttribute((const void*)gemm_tn_conv_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    return (int)hipFuncSetAttribute((const void*)gemm_tn_conv_kernel<SPLIT, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int T = a->kh * a->kw;
   const int blocks = a->splits * ((a->Cout + 127) / 128) * T * (a->Cin / 128);
-  hipLaunchKernelGGL((gemm_tn_conv_kernel<SPLIT>), dim3(blocks), dim3(256), SMEM, s, *a);
+  hipLaunchKernelGGL((gemm_tn_conv_kernel<SPLIT, NST>), dim3(blocks), dim3(256), SMEM, s, *a);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((int64_t)a->Cout * a->Cin * T)), dim3(256), 0, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
@@ -368,8 +385,9 @@ extern "C" int mvp_gemm_tn_conv(const mvp_gemm_tn_args* a, void* stream) {
   if ((a->ldg & 7) || (a->ldx & 7) || a->ldx < a->Cin || a->ldg < ((a->Cout + 127) / 128) * 128) return MVP_EINVAL;
   if (a->precision == MVP_PREC_BF16X3) {
     if (!a->g_lo || !a->x_lo) return MVP_EINVAL;
-    return launch_tn<3>(a, (hipStream_t)stream);
+    static const bool two = getenv("MVP_TN_STAGES") && atoi(getenv("MVP_TN_STAGES")) == 2;  // diagnostic A/B
+    return two ? launch_tn<3, 2>(a, (hipStream_t)stream) : launch_tn<3, 1>(a, (hipStream_t)stream);
   }
   if (a->precision != MVP_PREC_BF16) return MVP_EINVAL;
-  return launch_tn<1>(a, (hipStream_t)stream);
+  return launch_tn<1, 2>(a, (hipStream_t)stream);
 }
