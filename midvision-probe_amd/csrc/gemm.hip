@@ -23,6 +23,7 @@
 // SPLIT == 3 runs hi*hi + hi*lo + lo*hi (three MFMAs per tile) on bf16 pairs: operand error
 // ~2^-17 instead of 2^-9, which is what the reference's 1e-3 feature parity needs.
 #include "mvp_common.h"
+#include <cstdlib>
 
 // Diagnostic builds only (tools/gemm_bench.py compiles separate .so files with these set):
 //   MVP_ABLATE 1: no MFMA (fragments read and kept live), 2: no LDS-DMA after the first tile,
@@ -457,7 +458,10 @@ int launch_gemm_splitk(const mvp_gemm_args* a, hipStream_t s) {
 }
 
 // One tile rule for the split-K path (the workspace query must agree with the launch).
-inline bool splitk_wide(int N) { return N >= 1024; }
+inline bool splitk_wide(int N) {
+  static const int force = getenv("MVP_SPLITK_WIDE") ? atoi(getenv("MVP_SPLITK_WIDE")) : -1;  // diagnostic A/B
+  return force >= 0 ? force != 0 : N >= 1024;
+}
 
 }  // namespace
 
@@ -492,8 +496,8 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res;
   if (a->splitk > 1 && !ext) {  // (with the ReLU-gate / second-residual epilogues the request is ignored)
     if (a->splitk > 64 || a->K / 64 < a->splitk) return MVP_EINVAL;
-    if (splitk_wide(a->N)) return x3 ? launch_gemm_splitk<128, 128, 32, 3, 2>(a, s) : launch_gemm_splitk<128, 128, 64, 1, 2>(a, s);
-    return x3 ? launch_gemm_splitk<128, 64, 32, 3, 2>(a, s) : launch_gemm_splitk<128, 64, 64, 1, 2>(a, s);
+    if (splitk_wide(a->N)) return x3 ? launch_gemm_splitk<128, 128, 64, 3, 1>(a, s) : launch_gemm_splitk<128, 128, 64, 1, 2>(a, s);
+    return x3 ? launch_gemm_splitk<128, 64, 64, 3, 1>(a, s) : launch_gemm_splitk<128, 64, 64, 1, 2>(a, s);
   }
 #ifdef MVP_F_BM
   return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST>(a, s) : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST>(a, s);

@@ -29,7 +29,7 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
     """Mirror of the tile choice in csrc/gemm.hip -> template arguments BM,BN,BK,SPLIT,NSTAGE."""
     if splitk > 1:
         bn = 128 if N >= 1024 else 64
-        return f"128, {bn}, 32, 3, 2, splitk" if precision == PREC_BF16X3 else f"128, {bn}, 64, 1, 2, splitk"
+        return f"128, {bn}, 64, 3, 1, splitk" if precision == PREC_BF16X3 else f"128, {bn}, 64, 1, 2, splitk"
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     if precision == PREC_BF16X3:
         if N <= 256 and K >= 2048:
