@@ -50,6 +50,38 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erfv);
 }
 
+// Logical tile index -> (tm, tn), XCD-region-major.  xcd_remap() hands each XCD one contiguous slice of the logical
+// index space; here that space is enumerated region by region, the output being cut into XR x XC = 8 rectangles
+// chosen to minimise what one XCD must pull through its L2: rows(A)/XR + rows(W)/XC; when a slice needs more than
+// one round of resident workgroups, near-ties go to more column cuts (the smaller W share then stays L2-resident
+// across the rounds).  Inside a region tiles run row-major.
+// With plain row-major enumeration every XCD streamed ALL of W: fc1 fetched 164 MB from the memory side for 19 MB
+// of operands at 26 % L2 misses (profiles/r01_pmc_*).  Uneven divisions only shift a few tiles across slice
+// borders; the map stays a bijection.
+__device__ __forceinline__ void region_tile(int L, int TM, int TN, int M, int N, bool multi_round, int& tm, int& tn) {
+  int XR = 1;
+  long best = (long)M * 8 + N;  // 8 * (M / XR + N * XR / 8)
+#pragma unroll
+  for (int c = 2; c <= 8; c <<= 1) {
+    const long cost = (long)M * 8 / c + (long)N * c;
+    if (cost + (multi_round ? cost / 16 : 0) < best) { best = cost; XR = c; }
+  }
+  const int XC = 8 / XR;
+  for (int r = 0; r < 8; ++r) {
+    const int xr = r / XC, xc = r - xr * XC;
+    const int r0 = xr * TM / XR, r1 = (xr + 1) * TM / XR, c0 = xc * TN / XC, c1 = (xc + 1) * TN / XC;
+    const int w = c1 - c0, sz = (r1 - r0) * w;
+    if (L < sz) {
+      const int q = L / w;
+      tm = r0 + q;
+      tn = c0 + (L - q * w);
+      return;
+    }
+    L -= sz;
+  }
+  tm = TM - 1; tn = TN - 1;  // unreachable: the regions partition TM x TN
+}
+
 // CONV: the A operand is an implicit im2col of a channels-last activation [B, H, W, C]
 // (optionally a virtual nearest-upsample by 2^cup of the stored tensor): K index =
 // (ky*kw + kx)*C + c, output row m = (b, y, x) on the Ho x Wo grid.  A K-tile never straddles
@@ -82,7 +114,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   const int S = KSPLIT ? p.splitk : 1;
   const int bid = KSPLIT ? unit / S : unit;
   const int split = KSPLIT ? unit - bid * S : 0;
-  const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+  int tm, tn;
+  constexpr int SLOTS = 160 * 1024 / (NSTAGE * STAGE) > 8 ? 8 : 160 * 1024 / (NSTAGE * STAGE);  // resident workgroups per CU
+  const int tiles_m = (p.M + BM - 1) / BM;
+  region_tile(bid, tiles_m, tiles_n, p.M, p.N, tiles_m * tiles_n > 256 * SLOTS, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int nk_all = p.K / BK;
