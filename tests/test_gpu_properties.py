@@ -95,7 +95,7 @@ def test_resize_adjoint_identity(dev, mode, geom):
     xp = xc.permute(0, 3, 1, 2).contiguous()
     rp = torch.empty(Bn * C, Ho, Wo, device=dev)
     ops.resize(xp, rp, Bn * C, Hi, Wi, Ho, Wo, m)
-    assert torch.allclose(rp.view(Bn, C, Ho, Wo).permute(0, 2, 3, 1), rxc, rtol=0, atol=1e-6)
+    assert torch.allclose(rp.view(Bn, C, Ho, Wo).permute(0, 2, 3, 1), rxc, rtol=0, atol=2e-5)  # different (valid) association orders
 
 
 def test_tap_bn_moments_full_size(dev):
