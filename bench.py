@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (reference default batch_size: 16)")
     ap.add_argument("--image-size", default="224", help="S or HxW (480x640 = BASELINE config #2)")
     ap.add_argument("--precision", default=os.environ.get("MVP_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: batches start in host memory and go through mvp.prefetch.DevicePrefetcher (not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
@@ -161,6 +162,41 @@ def main():
     last_loss = float(loss_acc.item()) / max(args.warmup + args.steps, 1)
     images_per_s = world * B * args.steps / dt
 
+    # ---------------- optional PCIe-inclusive leg (never `value`): the same steps fed from HOST memory
+    h2d = None
+    if args.h2d:
+        from mvp.prefetch import DevicePrefetcher
+
+        def host_batch(step_idx):
+            g = torch.Generator().manual_seed(1000 * rank + step_idx)
+            images = torch.randn(B, 3, H, W, generator=g)
+            depth = torch.rand(B, 1, H, W, generator=g) * 9.9 + 0.05
+            depth[torch.rand(B, 1, H, W, generator=g) < 0.1] = 0.0
+            return {"image": images, "depth": depth}
+
+        hb = [host_batch(s) for s in range(n_distinct)]
+        res = {}
+        for label, pinned in (("pageable", False), ("pinned", True)):
+            src = [{k: (v.pin_memory() if pinned else v) for k, v in b.items()} for b in hb]
+            seq = [src[i % n_distinct] for i in range(args.warmup + args.steps)]
+            it = iter(DevicePrefetcher(seq, dev, depth=2))
+            for _ in range(args.warmup):
+                b = next(it)
+                loss_acc += train_depth_step(model, probe, opt, sched, loss_fn, b["image"], b["depth"])
+            barrier()
+            t1 = time.perf_counter()
+            for b in it:
+                loss_acc += train_depth_step(model, probe, opt, sched, loss_fn, b["image"], b["depth"])
+            barrier()
+            res[label] = round(world * B * args.steps / (time.perf_counter() - t1), 1)
+        sync_t = time.perf_counter()
+        for i in range(args.steps):  # the reference's way: blocking pageable .to(device) inside the step (train_depth.py:102-104)
+            b = hb[i % n_distinct]
+            loss_acc += train_depth_step(model, probe, opt, sched, loss_fn, b["image"].to(dev), b["depth"].to(dev))
+        barrier()
+        res["blocking_to_device"] = round(world * B * args.steps / (time.perf_counter() - sync_t), 1)
+        h2d = {"unit": "images/s", "note": "inputs start in host memory; DevicePrefetcher(depth=2) vs a blocking .to(device) per step", **res}
+
     gh, gw = -(-H // 16), -(-W // 16)
     N = 1 + gh * gw
     f_img = flops_per_image(N)
@@ -231,7 +267,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
                        "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
             "mean_loss": round(last_loss, 5),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, **({"h2d_inclusive": h2d} if h2d else {}),
         }
         print(json.dumps(out))
     if world > 1:

@@ -56,6 +56,18 @@ def train_snorm_step(model, probe, optimizer, scheduler, images, target, mask, d
     return loss.detach()
 
 
+def _device_batches(loader, dev, keys=("image", "depth", "snorm")):
+    """Wrap a host-side loader in the pinned double-buffered H2D prefetcher (mvp/prefetch.py); loaders that already
+    yield device tensors (or custom iterables) pass through."""
+    from torch.utils.data import DataLoader
+
+    from .prefetch import DevicePrefetcher
+
+    if isinstance(loader, DataLoader):
+        return DevicePrefetcher(loader, dev, depth=2, keys=keys)
+    return loader
+
+
 def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_model, loss_fn, rank=0, world_size=1,
           valid_loader=None, scale_invariant=False, wandb_use=False, is_final=False, is_navi=False, log_every=0):
     """Reference signature: train_depth.py:76-92.  Batches are dicts {"image", "depth"} (nyu.py:245-251)."""
@@ -67,7 +79,7 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
         if world_size > 1 and hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
             train_loader.sampler.set_epoch(ep)
         train_loss = 0.0
-        for i, batch in enumerate(train_loader):
+        for i, batch in enumerate(_device_batches(train_loader, dev)):
             images = batch["image"].to(dev, non_blocking=True)
             target = batch["depth"].to(dev, non_blocking=True).contiguous()
             loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model)
@@ -84,7 +96,7 @@ def validate(model, probe, loader, loss_fn, verbose=True, scale_invariant=False,
     dev = torch.device("cuda", torch.cuda.current_device())
     total_loss, sums, count = 0.0, {}, 0
     with torch.no_grad():
-        for batch in loader:
+        for batch in _device_batches(loader, dev):
             images = batch["image"].to(dev)
             target = batch["depth"].to(dev).contiguous()
             feats = model(images)

@@ -17,17 +17,6 @@ from mvp.optim import FlatAdamW  # noqa: E402
 from mvp.train import train_snorm_step  # noqa: E402
 
 
-def batches(n, B, hw, rank):
-    """Batch dict contract of evals/datasets/nyu.py:131-138: image, depth (mask = depth > 0), snorm."""
-    for s in range(n):
-        g = torch.Generator().manual_seed(1000 * rank + s)
-        img = torch.randn(B, 3, *hw, generator=g)
-        d = torch.rand(B, 1, *hw, generator=g) * 9.9 + 0.05
-        d[torch.rand(B, 1, *hw, generator=g) < 0.1] = 0
-        nrm = torch.randn(B, 3, *hw, generator=g)
-        yield {"image": img, "depth": d, "snorm": nrm / nrm.norm(dim=1, keepdim=True).clamp_min(1e-6)}
-
-
 def main(argv):
     from evals.utils.metrics import evaluate_surface_norm
     from evals.utils.optim import cosine_decay_linear_warmup
@@ -37,7 +26,12 @@ def main(argv):
     rank, local, world = mdist.env_setup("nccl")
     dev = torch.device("cuda", torch.cuda.current_device())
     ds = cfg["dataset"]
-    hw, nb, B = tuple(ds["image_size"]), ds["num_batches"], cfg["batch_size"]
+    from evals.datasets import build_loader
+    from mvp.prefetch import DevicePrefetcher
+
+    hw, B = tuple(ds["image_size"]), cfg["batch_size"]
+    loader = build_loader(dict(ds, batch_size=B), "train", B, num_gpus=world, num_workers=cfg.get("num_workers", 2))
+    nb = len(loader)
     model = config.instantiate(cfg["backbone"]).to(dev)
     probe = config.instantiate(cfg["probe"], feat_dim=model.feat_dim).to(dev)
     opt = FlatAdamW([{"params": probe.parameters(), "lr": cfg["optimizer"]["probe_lr"]}])
@@ -45,15 +39,17 @@ def main(argv):
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, n_ep * nb, cfg["optimizer"]["warmup_epochs"] * nb))
     for ep in range(n_ep):
         tot = 0.0
-        for batch in batches(nb, B, hw, rank):
-            images, target = batch["image"].to(dev), batch["snorm"].to(dev)
-            mask = batch["depth"].to(dev) > 0                       # train_snorm.py:95
+        if world > 1:
+            loader.sampler.set_epoch(ep)
+        for batch in DevicePrefetcher(loader, dev):
+            images, target = batch["image"], batch["snorm"]
+            mask = batch["depth"] > 0                               # train_snorm.py:95
             tot += train_snorm_step(model, probe, opt, sched, images, target, mask).item()
         if rank == 0:
             print(f"epoch {ep} train loss {tot / nb:.4f}")
     if rank == 0:
         model.eval(); probe.eval()
-        b = next(batches(1, B, hw, 99))
+        b = next(iter(build_loader(dict(ds, num_batches=1, batch_size=B), "valid", B)))
         with torch.no_grad():
             pred = MF.interpolate(probe(model(b["image"].to(dev))).contiguous(), size=hw, mode="bicubic")
         gm, _, _ = evaluate_surface_norm(pred, b["snorm"].to(dev), None, image_average=True, is_navi=True)

@@ -221,3 +221,29 @@ def test_spair_compute_errors_end_to_end(dev):
     np.testing.assert_allclose(e_same.numpy(), errors.diagonal()[both].numpy(), rtol=1e-5)
     np.testing.assert_allclose(e_nn.numpy(), errors[both].min(dim=1).values.numpy(), rtol=1e-5)
     np.testing.assert_array_equal(i_same.numpy(), both.nonzero().squeeze(1).numpy())
+
+
+@pytest.mark.parametrize("depth,workers", [(1, 0), (2, 0), (3, 2)])
+def test_device_prefetcher_order_and_buffer_reuse(dev, depth, workers):
+    """N3: batches arrive in loader order with exactly the host values, also when the host runs far ahead of the GPU
+    (no sync inside the loop; a long kernel keeps each batch's buffers busy while later batches are staged)."""
+    from evals.datasets import SyntheticNYU, build_loader
+    from mvp.prefetch import DevicePrefetcher
+
+    ds = SyntheticNYU("valid", num_samples=26, image_size=(64, 96))
+    host = [b for b in build_loader(ds, "valid", 4)]
+    pf = DevicePrefetcher(build_loader(ds, "valid", 4, num_workers=workers), dev, depth=depth)
+    assert len(pf) == len(host) == 7
+    big = torch.randn(2048, 2048, device=dev)
+    sums, keep = [], []
+    for b in pf:
+        assert b["image"].is_cuda and b["image"].dtype == torch.float32
+        for _ in range(6):  # keep the compute stream busy so that staging of later batches overlaps
+            big = (big @ big).mul_(1e-3).tanh_()
+        sums.append((b["image"].double().sum() + b["depth"].double().sum() * 3 + b["snorm"].double().sum() * 7))
+        keep.append(b["depth"][:, :, :2, :2].clone())
+    torch.cuda.synchronize()
+    for s, k, h in zip(sums, keep, host):
+        ref = h["image"].double().sum() + h["depth"].double().sum() * 3 + h["snorm"].double().sum() * 7
+        assert abs(s.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+        assert torch.equal(k.cpu(), h["depth"][:, :, :2, :2])
