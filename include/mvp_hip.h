@@ -141,7 +141,7 @@ typedef struct {
   const float* x; const float* gamma; const float* beta;
   mvp_bf16* out_hi; mvp_bf16* out_lo; /* lo may be NULL */
   float* out_f32;                     /* optional fp32 copy, or NULL */
-  int M, C;                           /* C % 4 == 0, C <= 2048 */
+  int M, C;                           /* C % 8 == 0, C <= 2048 */
   float eps;
 } mvp_layernorm_args;
 int mvp_layernorm_fwd(const mvp_layernorm_args*, void* stream);

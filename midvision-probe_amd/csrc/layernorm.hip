@@ -5,22 +5,25 @@
 
 namespace {
 
-constexpr int LN_MAXV = 8;  // float4 per lane: C <= 64 * 4 * 8 = 2048
+constexpr int LN_MAXV = 4;  // 8-element chunks per lane: C <= 64 * 8 * 4 = 2048
 
+// Each lane owns chunks of 8 consecutive elements (two float4 loads, ONE 16-byte store per output array: 8-byte
+// stores run at 0.5-0.7x the 16-byte rate on gfx950).
 __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.M) return;
-  const int nv = p.C >> 2;
+  const int nv = p.C >> 3;
   const float4* xr = (const float4*)(p.x + (size_t)row * p.C);
-  float4 v[LN_MAXV];
+  float4 v[LN_MAXV][2];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      v[i] = xr[c];
-      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      v[i][0] = xr[c * 2];
+      v[i][1] = xr[c * 2 + 1];
+      s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
     }
   }
   const float mean = wave_sum(s) / (float)p.C;
@@ -29,8 +32,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-      q += (a * a + b * b) + (cc * cc + d * d);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float a = v[i][h].x - mean, b = v[i][h].y - mean, cc = v[i][h].z - mean, d = v[i][h].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)p.C + p.eps);
@@ -40,16 +46,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      const float4 g = g4[c], b = b4[c];
-      float y[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
-                    (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
-      const size_t o = (size_t)row * p.C + c * 4;
-      uint16_t h[4], l[4];
+      float y[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split_bf16(y[e], h[e], l[e]);
-      *(u32x2_t*)(p.out_hi + o) = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
-      if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
-      if (p.out_f32) *(float4*)(p.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+      for (int h = 0; h < 2; ++h) {
+        const float4 g = g4[c * 2 + h], b = b4[c * 2 + h];
+        y[h * 4 + 0] = (v[i][h].x - mean) * rstd * g.x + b.x;
+        y[h * 4 + 1] = (v[i][h].y - mean) * rstd * g.y + b.y;
+        y[h * 4 + 2] = (v[i][h].z - mean) * rstd * g.z + b.z;
+        y[h * 4 + 3] = (v[i][h].w - mean) * rstd * g.w + b.w;
+      }
+      const size_t o = (size_t)row * p.C + c * 8;
+      uint16_t h[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
+      *(u32x4_t*)(p.out_hi + o) = u32x4_t{pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
+      if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])};
+      if (p.out_f32) {
+        *(float4*)(p.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
+        *(float4*)(p.out_f32 + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      }
     }
   }
 }
@@ -58,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
 
 extern "C" int mvp_layernorm_fwd(const mvp_layernorm_args* a, void* stream) {
   if (!a || !a->x || !a->gamma || !a->beta || !a->out_hi) return MVP_EINVAL;
-  if (a->M <= 0 || a->C <= 0 || (a->C & 3) || a->C > 64 * 4 * LN_MAXV) return MVP_EINVAL;
+  if (a->M <= 0 || a->C <= 0 || (a->C & 7) || a->C > 64 * 8 * LN_MAXV) return MVP_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
