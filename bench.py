@@ -203,14 +203,16 @@ def main():
 
     # ---------------- roofline leg: per-launch HIP-event timing of the dominant kernel (GEMM)
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:
+        # every rank runs these extra steps (the optimiser step holds the gradient all-reduce); rank 0 reports
         trace = []
         ops.set_trace(trace)
         nrep = 3
         for i in range(nrep):
             step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
+        barrier()
         ops.set_trace(None)
+    if not args.no_roofline and rank == 0:
         groups = {}
         for kind, tile, prec, flops, e0, e1 in trace:
             key = (kind, tile)
