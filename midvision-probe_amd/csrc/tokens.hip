@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const mvp_bn_tokens_args 
   {
     const int c = c0 + (t & 63);
     const float sc = (c < p.C) ? ss[c] : 0.f, sh = (c < p.C) ? ss[p.C + c] : 0.f;
+    if (p.cls_out && pt == 0 && t < 64 && c < p.C) p.cls_out[(size_t)b * p.C + c] = p.x[(size_t)b * p.N * p.C + c] * sc + sh;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int tp = i * 4 + (t >> 6), pp = p0 + tp;
@@ -319,7 +320,8 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   } else {
     hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
   }
-  if (a->nchw || a->tok_hi || a->tokT_hi) {
+  if (a->cls_out && a->N <= a->hw) return MVP_EINVAL;
+  if (a->nchw || a->tok_hi || a->tokT_hi || a->cls_out) {
     const int ptiles = (a->hw + 31) / 32;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(a->B * ptiles, (a->C + 63) / 64), dim3(256), 0, s, *a, ss);
   }

@@ -210,14 +210,25 @@ class ViTBackbone(nn.Module):
         eng = self.engine()
         bns, mode = self._tap_bn()
         with torch.no_grad():
-            taps = eng.forward_taps(images, self.multilayers, bn=bns, bn_mode=mode, tap_input_of_block=self.tap_input_of_block)
+            taps = eng.forward_taps(images, self.multilayers, bn=bns, bn_mode=mode, tap_input_of_block=self.tap_input_of_block,
+                                    want_cls=self.output in ("cls", "dense-cls"))
             if self.add_norm and self.training:
                 torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms], 1)  # one launch for all taps
         return taps
 
     def _finish(self, taps: TapOutputs):
-        """tokens_to_output for the non-'dense' output types needs the (normalised) CLS token,
-        which the fused tap kernel does not emit: those types are not supported on the HIP path."""
+        """tokens_to_output (evals/models/utils.py:105-124) per tap.  'dense' is the kernel's own output; 'cls' is the
+        (tap-normalised) CLS token the tap kernel emits next to the map; 'gap' / 'dense-cls' are shape glue on those."""
+        if self.output == "dense":
+            outs = list(taps)
+        elif self.output == "cls":
+            outs = list(taps.cls)
+        elif self.output == "gap":
+            outs = [t.mean(dim=(2, 3)) for t in taps]
+        elif self.output == "dense-cls":
+            outs = [torch.cat((t, c[:, :, None, None].expand(-1, -1, t.shape[2], t.shape[3])), dim=1).contiguous() for t, c in zip(taps, taps.cls)]
+        else:
+            raise ValueError(f"unknown output type {self.output!r}")
         if self.output != "dense":
-            raise NotImplementedError(f"output={self.output!r}: only 'dense' feature maps are produced by the HIP path")
+            return outs[0] if len(outs) == 1 else outs
         return taps[0] if len(taps) == 1 else taps

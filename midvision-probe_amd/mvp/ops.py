@@ -154,12 +154,12 @@ def bn_tokens_workspace_bytes(M: int, Cdim: int) -> int:
 
 def bn_tokens_to_nchw(x, B, N, Cdim, hw, *, workspace, stats=None, gamma=None, beta=None, running_mean=None, running_var=None,
                       nchw=None, tok: Optional[Pair] = None, ld_tok=0, col_off=0, tokT: Optional[Pair] = None, ldT=0,
-                      eps=1e-5, momentum=0.1, mode=0) -> None:
+                      eps=1e-5, momentum=0.1, mode=0, cls_out=None) -> None:
     t_hi, t_lo = tok if tok is not None else (None, None)
     tt_hi, tt_lo = tokT if tokT is not None else (None, None)
     a = lib.BnTokensArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(running_mean), lib.ptr(running_var), lib.ptr(stats),
                          lib.ptr(nchw), lib.ptr(t_hi), lib.ptr(t_lo), ld_tok, col_off, lib.ptr(tt_hi), lib.ptr(tt_lo), ldT,
-                         lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode)
+                         lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode, lib.ptr(cls_out))
     lib.call("mvp_bn_tokens_to_nchw_fwd", a)
 
 

@@ -202,7 +202,7 @@ class ViTEngine:
         ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=pr)
 
     def forward_taps(self, images: torch.Tensor, layers: Sequence[int], *, bn: Optional[Sequence[dict]] = None,
-                     bn_mode: int = 0, pack: bool = True, tap_input_of_block: bool = False) -> TapOutputs:
+                     bn_mode: int = 0, pack: bool = True, tap_input_of_block: bool = False, want_cls: bool = False) -> TapOutputs:
         """Run blocks up to the last tapped one; at each tap apply the (train-mode) tap BN and
         emit the NCHW map (+ token-major packing).  ``bn[j]`` = dict(weight,bias,running_mean,
         running_var) tensors or None; bn_mode: 0 train stats, 1 eval, 2 no norm.
@@ -222,15 +222,20 @@ class ViTEngine:
             packed.generation += 1
         stats = torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device)
 
+        outs.cls = []
+
         def tap(j):
             nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
+            cls = torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None
+            if want_cls:
+                outs.cls.append(cls)
             b = bn[j] if bn is not None else None
             ops.bn_tokens_to_nchw(
                 ws["x"], B, N, C, hw, workspace=ws["bn_ws"], stats=stats[j],
                 gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                 running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                 nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
-                mode=bn_mode)
+                mode=bn_mode, cls_out=cls)
             outs.append(nchw)
 
         last = max(layers)

@@ -247,3 +247,24 @@ def test_device_prefetcher_order_and_buffer_reuse(dev, depth, workers):
         ref = h["image"].double().sum() + h["depth"].double().sum() * 3 + h["snorm"].double().sum() * 7
         assert abs(s.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
         assert torch.equal(k.cpu(), h["depth"][:, :, :2, :2])
+
+
+@pytest.mark.parametrize("output", ["cls", "gap", "dense-cls"])
+@pytest.mark.parametrize("add_norm", [False, True])
+def test_dino_output_types_vs_oracle(dev, output, add_norm):
+    """tokens_to_output variants (evals/models/utils.py:105-124): the CLS token comes normalised out of the tap kernel,
+    'gap' / 'dense-cls' are shape glue.  ViT-B/16, 4 taps, B=3 at 96x128 (non-square), train-mode tap BN."""
+    from evals.models.dino import DINO
+    from oracle import vit as ovit
+
+    vsd = ovit.make_vit_weights(seed=4)
+    g = torch.Generator().manual_seed(9)
+    images = torch.randn(3, 3, 96, 128, generator=g)
+    ref = ovit.vit_dense_features(vsd, images, ovit.multilayer_indices(12), heads=12, patch=16, add_norm=add_norm, output=output)
+    model = DINO(return_multilayer=True, add_norm=add_norm, output=output, weights=vsd).to(dev)
+    outs = model(images.to(dev))
+    C2 = 1536 if output == "dense-cls" else 768
+    assert model.feat_dim == [C2] * 4 and len(outs) == 4
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape and (o.shape == (3, C2, 6, 8) if output == "dense-cls" else o.shape == (3, 768))
+        assert rel_l2(o.cpu().numpy(), r.numpy()) < 1e-3
