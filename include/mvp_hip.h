@@ -301,14 +301,16 @@ int mvp_colsum(const mvp_colsum_args*, void* stream);
 /* ------------------------------------------------------------------------------------
  * Fused AdamW over a flat fp32 parameter buffer (torch.optim.AdamW defaults,
  * train_depth.py:624-627): decoupled weight decay, bias correction, eps outside sqrt.
- * lr / step are read from DEVICE scalars so the op is graph-capturable:
- *   hyper[0] = lr, hyper[1] = 1 - beta1^t, hyper[2] = 1 - beta2^t.
+ * Schedule state: hyper == NULL -> lr, bias_c1 = 1 - beta1^t, bias_c2 = 1 - beta2^t are taken BY VALUE from the
+ * struct (no host->device staging that a host running ahead of the stream could overwrite);
+ * hyper != NULL -> device scalars hyper[0..2] = {lr, bias_c1, bias_c2} (replay of a captured hipGraph).
  * grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
   const float* hyper; int64_t n;
   float beta1, beta2, eps, weight_decay, grad_scale;
+  float lr, bias_c1, bias_c2;
 } mvp_adamw_args;
 int mvp_adamw_step(const mvp_adamw_args*, void* stream);
 

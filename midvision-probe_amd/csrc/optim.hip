@@ -1,12 +1,12 @@
 // Fused AdamW over a flat fp32 parameter buffer (torch.optim.AdamW defaults as used by
-// train_depth.py:624-627).  lr and the bias corrections come from DEVICE scalars so that the
-// launch is capturable into a hipGraph and replayable with a changing schedule.
+// train_depth.py:624-627).  lr and the bias corrections travel BY VALUE with the launch (hyper == NULL), or come
+// from device scalars (hyper != NULL) for a caller that replays a captured hipGraph with a changing schedule.
 #include "mvp_common.h"
 
 namespace {
 
 __global__ __launch_bounds__(256) void adamw_kernel(const mvp_adamw_args p) {
-  const float lr = p.hyper[0], bc1 = p.hyper[1], bc2 = p.hyper[2];
+  const float lr = p.hyper ? p.hyper[0] : p.lr, bc1 = p.hyper ? p.hyper[1] : p.bias_c1, bc2 = p.hyper ? p.hyper[2] : p.bias_c2;
   const float step_size = lr / bc1;
   const float rbc2 = 1.0f / sqrtf(bc2);
   const float decay = 1.0f - lr * p.weight_decay;
@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const mvp_adamw_args p) {
 }  // namespace
 
 extern "C" int mvp_adamw_step(const mvp_adamw_args* a, void* stream) {
-  if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || !a->hyper || a->n <= 0) return MVP_EINVAL;
+  if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || a->n <= 0) return MVP_EINVAL;
+  if (!a->hyper && !(a->bias_c1 > 0.f && a->bias_c2 > 0.f)) return MVP_EINVAL;
   if (((uintptr_t)a->param | (uintptr_t)a->grad | (uintptr_t)a->exp_avg | (uintptr_t)a->exp_avg_sq) & 15) return MVP_EINVAL;
   int64_t g = ((a->n >> 2) + 255) / 256;
   if (g < 1) g = 1;

@@ -107,7 +107,8 @@ class ColsumArgs(C.Structure):
 
 class AdamWArgs(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("hyper", _vp), ("n", _i64),
-                ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("grad_scale", _f)]
+                ("beta1", _f), ("beta2", _f), ("eps", _f), ("weight_decay", _f), ("grad_scale", _f),
+                ("lr", _f), ("bias_c1", _f), ("bias_c2", _f)]
 
 
 class CorrArgmaxArgs(C.Structure):

@@ -211,8 +211,11 @@ def colsum(x, out, M, N, ld=None, accumulate=False, workspace=None) -> None:
                                           lib.ptr(workspace), workspace.numel() * workspace.element_size()))
 
 
-def adamw_step(param, grad, exp_avg, exp_avg_sq, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0) -> None:
-    a = lib.AdamWArgs(lib.ptr(param), lib.ptr(grad), lib.ptr(exp_avg), lib.ptr(exp_avg_sq), lib.ptr(hyper), n, beta1, beta2, eps, weight_decay, grad_scale)
+def adamw_step(param, grad, exp_avg, exp_avg_sq, hyper, n, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0,
+               lr=0.0, bias_c1=0.0, bias_c2=0.0) -> None:
+    """hyper: device tensor {lr, 1-beta1^t, 1-beta2^t} or None (then lr / bias_c1 / bias_c2 go by value)."""
+    a = lib.AdamWArgs(lib.ptr(param), lib.ptr(grad), lib.ptr(exp_avg), lib.ptr(exp_avg_sq), lib.ptr(hyper), n, beta1, beta2, eps, weight_decay, grad_scale,
+                      lr, bias_c1, bias_c2)
     lib.call("mvp_adamw_step", a)
 
 

@@ -45,8 +45,6 @@ class FlatAdamW(torch.optim.Optimizer):
         self._params = plist
         self._n = total
         self._step = 0
-        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(4)
         self.process_group = process_group
         self.world_size = world_size
 
@@ -85,10 +83,9 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._step += 1
         b1, b2 = g["betas"]
-        self._hyper_host[0] = float(g["lr"])
-        self._hyper_host[1] = 1.0 - b1 ** self._step
-        self._hyper_host[2] = 1.0 - b2 ** self._step
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
-        ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self._hyper, self._n,
-                       beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"], grad_scale=1.0 / world)
+        # schedule state goes BY VALUE with the launch: a pinned staging buffer would be overwritten by a host that
+        # runs several steps ahead of the stream before the earlier async copy has read it
+        ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, None, self._n,
+                       beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"], grad_scale=1.0 / world,
+                       lr=float(g["lr"]), bias_c1=1.0 - b1 ** self._step, bias_c2=1.0 - b2 ** self._step)
         return None

@@ -175,3 +175,40 @@ def test_spair_self_correspondence_800(dev):
     xy, val = spair.correspondence(f, f, kp)
     assert torch.equal(xy.cpu(), torch.stack((cols, rows), dim=1))
     assert (val.cpu() - 1.0).abs().max().item() < 1e-4
+
+
+def test_trajectory_independent_of_host_syncs(dev):
+    """The host may run many steps ahead of the stream (bench.py never syncs inside the timed loop): nothing on the path
+    may read host-staged state late.  6 steps with a sync after every step == 6 steps enqueued back to back, bit for bit
+    (this caught an AdamW schedule buffer that was staged through pinned memory)."""
+    from evals.models.dino import DINO
+    from evals.models.probes import DepthHead
+    from evals.utils.losses import DepthLoss
+    from evals.utils.optim import cosine_decay_linear_warmup
+    from mvp.optim import FlatAdamW
+    from mvp.train import train_depth_step
+    from oracle import train as otrain
+    from oracle import vit as ovit
+
+    vsd = ovit.make_vit_weights(seed=2)
+    batches = []
+    for s in range(3):
+        im, tg = otrain.synthetic_depth_batch(8, 224, 224, rank=0, step=s)
+        batches.append((im.to(dev), tg.to(dev)))
+    finals = []
+    for sync in (True, False):
+        torch.manual_seed(0)
+        model = DINO(return_multilayer=True, add_norm=True, weights=vsd).to(dev)
+        probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth").to(dev)
+        opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-3}])
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 20, 4))
+        losses = []
+        for i in range(6):
+            im, tg = batches[i % 3]
+            losses.append(train_depth_step(model, probe, opt, sched, DepthLoss(), im, tg.clone()))
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append((torch.stack(losses).cpu(), probe.head.conv.weight.detach().clone(), probe.head.conv.bias.detach().clone()))
+    assert torch.equal(finals[0][0], finals[1][0])
+    assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
