@@ -31,6 +31,12 @@
 #ifndef MVP_ABLATE
 #define MVP_ABLATE 0
 #endif
+// MVP_S1_REGBUF 1: single-stage loop double-buffered through registers (fragments of tile kt read out, then the DMA of
+// tile kt+1 flies under the MFMAs).  Measured +-3 % against the plain loop (the extra VGPRs cost a resident
+// workgroup on the 64x128 / 64x64 tiles), so the shipped default is the plain loop.
+#ifndef MVP_S1_REGBUF
+#define MVP_S1_REGBUF 0
+#endif
 
 namespace {
 
@@ -250,8 +256,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
     };
 
   if constexpr (NSTAGE == 1) {
-    // Single LDS buffer (BK = 64: whole 128-byte lines per LDS-DMA row -> half the L2 requests of BK = 32): no
-    // intra-workgroup prefetch; the 2-3 co-resident workgroups of a CU overlap each other's load and MFMA phases.
+    // Single LDS buffer (BK = 64: whole 128-byte lines per LDS-DMA row -> half the L2 requests of BK = 32); the 2-5
+    // co-resident workgroups of a CU overlap each other's load and MFMA phases.
+#if MVP_S1_REGBUF
+    bf16x8_t fa_hi[KS][MT], fa_lo[KS][MT], fw_hi[KS][NT], fw_lo[KS][NT];
+    const char* ab = smem + (wm0 + frow) * ROWB;
+    const char* wb = smem + A_BYTES * NARR + (wn0 + frow) * ROWB;
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile kt has landed (everybody's pieces)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int coff = (((ks << 2) + fq) ^ fsw) << 4;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          fa_hi[ks][j] = *(const bf16x8_t*)(ab + j * 16 * ROWB + coff);
+          if (SPLIT == 3) fa_lo[ks][j] = *(const bf16x8_t*)(ab + A_BYTES + j * 16 * ROWB + coff);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          fw_hi[ks][i] = *(const bf16x8_t*)(wb + i * 16 * ROWB + coff);
+          if (SPLIT == 3) fw_lo[ks][i] = *(const bf16x8_t*)(wb + W_BYTES + i * 16 * ROWB + coff);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everybody holds its fragments: the buffer is free
+      if (kt + 1 < nk) stage(0, kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j) {
+            if (SPLIT == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw_lo[ks][i], fa_hi[ks][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw_hi[ks][i], fa_lo[ks][j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw_hi[ks][i], fa_hi[ks][j], acc[i][j], 0, 0, 0);
+          }
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
       if (kt > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -262,6 +307,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       __builtin_amdgcn_s_barrier();
       mma_tile(smem);
     }
+#endif
   } else {
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + NSTAGE - 2 < nk) {

@@ -25,7 +25,8 @@ def main():
     def cfg(bm, bn, bk, st):
         return build(0, f"-DMVP_F_BM={bm} -DMVP_F_BN={bn} -DMVP_F_BK={bk} -DMVP_F_ST={st}")
     if "--tiles" in sys.argv:
-        for c in ((128,128,32,2),(128,64,32,2),(128,128,64,1),(128,64,64,1),(64,64,64,1),(128,128,32,1),(64,128,64,1)):
+        variants["plain_s1"] = build(0, "-DMVP_S1_REGBUF=0")
+        for c in ((128,128,64,1),(64,128,64,1),(128,64,64,1),(64,64,64,1)):
             try:
                 variants["%dx%dk%ds%d" % c] = cfg(*c)
             except Exception as e:
