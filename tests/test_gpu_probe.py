@@ -270,3 +270,34 @@ def test_train_step_vitb16_vs_oracle(dev, precision, tol_loss, tol_grad):
     gw = probe.head.conv.weight.grad.cpu().numpy()
     assert rel_l2(gw, tr.probe_sd["head.conv.weight"].grad.numpy()) < tol_grad
     assert rel_l2(probe.head.conv.bias.grad.cpu().numpy(), tr.probe_sd["head.conv.bias"].grad.numpy()) < tol_grad
+
+
+def test_losses_degenerate_masks_match_reference_semantics(dev):
+    """Edge cases of the masked losses (losses.py:54-74,157-182): no valid pixel -> the reference's mean over an empty
+    selection is NaN (and so is ours, with finite zero gradients); a single valid pixel is a regular value."""
+    from evals.utils.losses import DepthLoss, angular_loss
+    from oracle import losses as ol
+
+    g = torch.Generator().manual_seed(0)
+    pred = torch.rand(2, 1, 32, 48, generator=g) * 5 + 0.1
+    one = torch.zeros(2, 1, 32, 48)
+    one[0, 0, 3, 5] = 2.0
+    for tgt in (torch.zeros(2, 1, 32, 48), one, torch.full((2, 1, 32, 48), 11.0)):
+        p = pred.clone().to(dev).requires_grad_(True)
+        loss = DepthLoss()(p, tgt.clone().to(dev))
+        loss.backward()
+        ref = ol.depth_loss(pred.clone(), tgt.clone())
+        assert torch.isnan(loss).item() == torch.isnan(ref).item()
+        if not torch.isnan(ref):
+            assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+        assert not torch.isnan(p.grad).any()
+    pn = torch.randn(2, 4, 16, 16, generator=g)
+    gt = torch.nn.functional.normalize(torch.randn(2, 3, 16, 16, generator=g), dim=1)
+    m1 = torch.zeros(2, 1, 16, 16, dtype=torch.bool)
+    m1[1, 0, 2, 3] = True
+    for mask in (torch.zeros(2, 1, 16, 16, dtype=torch.bool), m1):
+        loss = angular_loss(pn.to(dev), gt.to(dev), mask.to(dev), uncertainty_aware=True)
+        ref = ol.angular_loss(pn, gt, mask, uncertainty_aware=True)
+        assert torch.isnan(loss).item() == torch.isnan(ref).item()
+        if not torch.isnan(ref):
+            assert abs(loss.item() - ref.item()) < 1e-5 * max(abs(ref.item()), 1e-3)
