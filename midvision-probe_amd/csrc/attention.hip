@@ -5,9 +5,10 @@
 //                            32 query rows and sweeps the keys in 64-key tiles staged cooperatively into LDS by
 //                            LDS-DMA (global_load_lds, 16 B/lane), double-buffered.
 //   attention_resident_kernel N <= 256 (the 224^2 / 197-token case): grid = B*H; a workgroup = 8 waves = all
-//                            query rows of one (batch, head); ALL keys and values are staged once (<= 128 KB),
-//                            one barrier, then every wave runs its tiles back to back.  K/V are read from
-//                            L2 once per head instead of once per query block and no wave ever waits for a tile.
+//                            query rows of one (batch, head); ALL keys and values are staged once (<= 128 KB):
+//                            tile 0 + Q, barrier, the remaining tiles land under tile 0's compute, one more
+//                            barrier, then every wave runs its tiles back to back.  K/V are read from L2 once
+//                            per head instead of once per query block.
 //
 // MFMA orientation ("swapped", so nothing crosses lanes between the two products):
 //   S^T[key, q] = K . Q^T     A operand = K fragment (ds_read_b128 from the swizzled K tile),
@@ -255,18 +256,24 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
   const int q0 = wave * 32;
   const int nkt = (p.N + 63) >> 6;
   const size_t rowbase = (size_t)b * p.N;
-  // 8 waves x 8 rows = one 64-key tile per pass
-  for (int kt = 0; kt < nkt; ++kt) {
-    char* base = smem + kt * STAGE;
-    attn_stage_piece<SPLIT>(p, rowbase, h, kt * 64, wave * 8, base, base + NARR * TILE, lane);
-  }
+  // 8 waves x 8 rows = one 64-key tile per pass.  Tile 0 and Q first; the other tiles (3/4 of the bytes at N = 197)
+  // are issued behind the first barrier and land while tile 0 is being computed.
+  attn_stage_piece<SPLIT>(p, rowbase, h, 0, wave * 8, smem, smem + NARR * TILE, lane);
   AttnState<SPLIT> st;
   attn_load_q<SPLIT>(st, p, rowbase, q0, h, lane);
   const float cs = p.scale * 1.44269504088896340736f;
+  const bool active = q0 < p.N;  // wave-uniform
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (q0 >= p.N) return;  // wave-uniform; no barrier follows
-  for (int kt = 0; kt < (MVP_ATT_ABLATE == 5 ? 0 : nkt); ++kt) {
+  for (int kt = 1; kt < nkt; ++kt) {
+    char* base = smem + kt * STAGE;
+    attn_stage_piece<SPLIT>(p, rowbase, h, kt * 64, wave * 8, base, base + NARR * TILE, lane);
+  }
+  if (active && MVP_ATT_ABLATE != 5) attn_tile<SPLIT>(st, smem, smem + NARR * TILE, 0, p.N, nkt == 1, cs, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (!active) return;  // no barrier follows
+  for (int kt = 1; kt < (MVP_ATT_ABLATE == 5 ? 0 : nkt); ++kt) {
     const char* kb = smem + kt * STAGE;
     attn_tile<SPLIT>(st, kb, kb + NARR * TILE, kt * 64, p.N, kt == nkt - 1, cs, lane);
   }

@@ -100,32 +100,32 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   o[0] = shift; o[1] = s1; o[2] = s2;
 }
 
-// Pass 2: a workgroup = 64 channels x 16 slab groups (coalesced 768-B reads of the [slab][channel][3] partials).
-// Each thread folds its slabs (stride 16) into fp64 moments about the channel's first-slab shift (no per-slab
-// division; fp64 keeps the centred second moment exact to ~1e-13 relative), the 16 groups are combined through LDS
-// in a fixed order (deterministic) -> mean, biased var; running stats (momentum, unbiased var) and the affine
-// scale/shift used by the apply pass.
-constexpr int BN_FG = 16;
+// Pass 2: a workgroup = 16 channels x 64 slab groups (48 workgroups at C = 768, so the 3.6 MB of partials are pulled
+// by 48 CUs instead of 12).  Each thread folds its slabs (stride 64) into fp64 moments about the channel's
+// first-slab shift (no per-slab division; fp64 keeps the centred second moment exact to ~1e-13 relative), the 64
+// groups are combined through LDS in a fixed order (deterministic) -> mean, biased var; running stats (momentum,
+// unbiased var) and the affine scale/shift used by the apply pass.
+constexpr int BN_FC = 16, BN_FG = 64;
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
                                                            float* __restrict__ ss, int M, int nslab) {
-  __shared__ double red[BN_FG][64][2];
-  const int lc = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lc;
+  __shared__ double red[BN_FG][BN_FC][2];
+  const int lc = threadIdx.x & (BN_FC - 1), grp = threadIdx.x / BN_FC;
+  const int c = blockIdx.x * BN_FC + lc;
   const bool ok = c < p.C;
   const double ref = ok ? (double)part[(size_t)c * 3] : 0.0;  // slab 0's shift: common origin of the moments
   double s1 = 0.0, s2 = 0.0;
   if (ok) {
-    for (int s0 = grp; s0 < nslab; s0 += BN_FG * 8) {
-      float o0[8], o1[8], o2[8];
+    for (int s0 = grp; s0 < nslab; s0 += BN_FG * 4) {
+      float o0[4], o1[4], o2[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {  // 24 independent loads in flight
+      for (int u = 0; u < 4; ++u) {  // 12 independent loads in flight
         const int s = min(s0 + u * BN_FG, nslab - 1);
         const float* o = part + ((size_t)s * p.C + c) * 3;
         o0[u] = o[0]; o1[u] = o[1]; o2[u] = o[2];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 4; ++u) {
         const int s = s0 + u * BN_FG;
         if (s < nslab) {
           const double nb = (double)min(BN_RB, M - s * BN_RB);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_a
   __syncthreads();
   if (grp != 0 || !ok) return;
   s1 = 0.0; s2 = 0.0;
-#pragma unroll
+#pragma unroll 8
   for (int g = 0; g < BN_FG; ++g) { s1 += red[g][lc][0]; s2 += red[g][lc][1]; }
   const double n = (double)M;
   const double dm = s1 / n;
@@ -316,7 +316,7 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   float* ss = part + (size_t)nslab * a->C * 3;
   if (a->mode == 0) {
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab, (a->C + 255) / 256), dim3(256), 0, s, a->x, part, M, a->C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + 63) / 64), dim3(1024), 0, s, *a, part, ss, M, nslab);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + BN_FC - 1) / BN_FC), dim3(1024), 0, s, *a, part, ss, M, nslab);
   } else {
     hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
   }
