@@ -99,8 +99,9 @@ __device__ __forceinline__ void region_tile(int L, int TM, int TN, int M, int N,
 // its tile, stores the raw accumulators to the workspace and bumps the tile's counter; the unit that arrives LAST
 // (no unit ever waits) sums all S partials in the fixed order 0..S-1 (deterministic whichever unit does it) and
 // runs the normal fused epilogue.  The counter resets itself for the next launch.
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT, bool KSPLIT = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
+// NW = waves per workgroup (4: 2x2 wave grid; 8: 4x2, i.e. the same tile cut into more, smaller wave tiles).
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT, bool KSPLIT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   static_assert(!(KSPLIT && (CONV || EXT)), "split-K is compiled for the plain linear GEMMs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   constexpr int A_BYTES = BM * ROWB;
   constexpr int W_BYTES = BN * ROWB;
   constexpr int STAGE = (A_BYTES + W_BYTES) * NARR;
-  constexpr int WM = BM / 2, WN = BN / 2;  // per-wave output tile (2x2 waves)
+  constexpr int WM = BM / (NW / 2), WN = BN / 2;  // per-wave output tile ((NW/2) x 2 waves)
+  constexpr int NT_THREADS = NW * 64;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int KS = BK / 32;              // MFMA k-steps per tile
 
@@ -138,13 +140,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   const int csw = (BK == 64) ? (rsub & 7) : ((0x1320 >> (((rsub >> 2) & 3) * 4)) & 3);
   const int csrc = (((lane % CH) ^ csw)) << 3;  // swizzled source chunk, in elements
 
-  constexpr int APASS = BM / (4 * RPP);
+  constexpr int APASS = BM / (NW * RPP);
+  static_assert(BM % (NW * RPP) == 0 && BN % (NW * RPP) == 0 && (WM / 16) % 2 == 0, "tile / wave-count combination");
   int cvb[APASS], cvy[APASS], cvx[APASS];  // conv: image index and top-left input coords of this lane's rows
   int ct_ky = 0, ct_kx = 0, ct_c0 = 0;     // conv: (tap, channel) position of the next tile to stage
   if (CONV) {
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      const int m = min(m0 + ps * 4 * RPP + wave * RPP + rsub, p.M - 1);
+      const int m = min(m0 + ps * NW * RPP + wave * RPP + rsub, p.M - 1);
       const int x = m % p.cWo, t = m / p.cWo;
       cvb[ps] = t / p.cHo;
       cvy[ps] = (t % p.cHo) * p.cstride - p.cpad;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
     const int k0 = (kt0 + kt) * BK;
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
-      const int r = ps * 4 * RPP + wave * RPP;
+      const int r = ps * NW * RPP + wave * RPP;
       if (CONV) {
         const int yy = cvy[ps] + ct_ky, xx = cvx[ps] + ct_kx;
         const bool ok = ((unsigned)yy < (unsigned)p.cH) && ((unsigned)xx < (unsigned)p.cW);
@@ -186,8 +189,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
     }
     char* wb = base + A_BYTES * NARR;
 #pragma unroll
-    for (int ps = 0; ps < BN / (4 * RPP); ++ps) {
-      const int r = ps * 4 * RPP + wave * RPP;
+    for (int ps = 0; ps < BN / (NW * RPP); ++ps) {
+      const int r = ps * NW * RPP + wave * RPP;
       const int grow = min(n0 + r + rsub, p.N - 1);
       const size_t off = (size_t)grow * p.ldw + k0 + csrc;
       __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_hi + off), LDS_PTR(wb + r * ROWB), 16, 0, 0);
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   // raw s_barrier (everybody's pieces landed AND everybody finished reading tile kt-1, whose
   // buffer is the one restaged next) -> issue tile kt+NSTAGE-1 -> MFMAs on tile kt.
   // __syncthreads() is NOT used in the loop: its fence would drain the in-flight LDS-DMA.
-  constexpr int LOADS = (BM / (4 * RPP) + BN / (4 * RPP)) * NARR;  // LDS-DMA instructions per wave per tile
+  constexpr int LOADS = (BM / (NW * RPP) + BN / (NW * RPP)) * NARR;  // LDS-DMA instructions per wave per tile
 #pragma unroll
   for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
     if (s0 < nk) stage(s0, s0);
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
     // all partials back with `sc1` loads after a workgroup barrier (MI355X_MICROARCH.md, hand-off table).
     int* ctr = (int*)p.splitk_ws;
     constexpr int NACC = NT * MT;
-    constexpr int UNIT_BYTES = NACC * 256 * 16;  // [acc register][thread] float4: 1-KiB wave accesses
+    constexpr int UNIT_BYTES = NACC * NT_THREADS * 16;  // [acc register][thread] float4: 1-KiB wave accesses
     char* part = (char*)p.splitk_ws + SPLITK_CTR_BYTES;
     constexpr int AUX_SC1 = 16;  // gfx940+ cache policy bit 4
     {
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, ((i * MT + j) * 256 + tid) * 16, 0, AUX_SC1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, ((i * MT + j) * NT_THREADS + tid) * 16, 0, AUX_SC1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __shared__ int s_last;
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          const f32x4_t t = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((i * MT + j) * 256 + tid) * 16, 0, AUX_SC1));
+          const f32x4_t t = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((i * MT + j) * NT_THREADS + tid) * 16, 0, AUX_SC1));
           acc[i][j] = (sp == 0) ? t : acc[i][j] + t;
         }
     }
@@ -486,22 +489,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mvp_gemm_args p) {
   }
 }
 
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE>
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, int NW = 4>
 constexpr int gemm_smem() {
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int stages = NSTAGE * (BM + BN) * BK * 2 * NARR;
-  constexpr int epi = 4 * 32 * (BN / 2 + 4) * 4;
+  constexpr int epi = NW * 32 * (BN / 2 + 4) * 4;
   return stages > epi ? stages : epi;
 }
 
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV = false>
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV = false, int NW = 4>
 int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
-  constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE>();
+  constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE, NW>();
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static int configured = [] {
-    int e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false>,
+    int e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false, false, NW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true>,
+    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     return e;
   }();
@@ -509,9 +512,9 @@ int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res;
   if (ext)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true>), dim3(tiles), dim3(256), SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false>), dim3(tiles), dim3(256), SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false, false, NW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
@@ -568,7 +571,7 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     // A K-tile must stay inside one tap: BK = 64 (whole-line rows, single stage: see the tile notes below) when
     // C % 64 == 0, else BK = 32 (any C % 32 == 0), two stages.
     if (x3 && (a->cC & 63) == 0) {
-      if (a->N > 64) return launch_gemm<128, 128, 64, 3, 1, true>(a, s);
+      if (a->N > 64) return launch_gemm<128, 128, 64, 3, 1, true, 8>(a, s);
       return launch_gemm<128, 64, 64, 3, 1, true>(a, s);
     }
     if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
@@ -581,7 +584,11 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     return x3 ? launch_gemm_splitk<128, 64, 64, 3, 1>(a, s) : launch_gemm_splitk<128, 64, 64, 1, 2>(a, s);
   }
 #ifdef MVP_F_BM
-  return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST>(a, s) : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST>(a, s);
+#ifndef MVP_F_NW
+#define MVP_F_NW 4
+#endif
+  return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST, false, MVP_F_NW>(a, s)
+            : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST, false, MVP_F_NW>(a, s);
 #else
   // Tile choice, split mode (measured on MI355X, tools/gemm_bench.py --tiles at M = 3152 and M = 12608; us, old -> new):
   //   qkv 41.3 -> 37.2 / 150.8 -> 138.6, proj 21.1 -> 17.2 / 63.7 -> 49.5, fc1 62.7 -> 51.3 / 193.8 -> 180.6,
@@ -600,7 +607,9 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     if (a->N >= 1024) {
       // one round of 128x128 tiles (2 resident per CU = 512 slots) or many rounds: big tiles; in between the
       // second, mostly empty round costs more than the smaller tile's extra operand traffic
-      if (t128 <= 512 || t128 >= 1536) return launch_gemm<128, 128, 64, 3, 1>(a, s);
+      // 8 waves (4x2) on the 128x128 tile: same LDS / residency, 4 waves per SIMD hide the load phase better
+      // (M = 12608: qkv 136.0 -> 128.4 us, fc1 168.2 -> 164.5; M = 3152: 39.0 -> 38.4)
+      if (t128 <= 512 || t128 >= 1536) return launch_gemm<128, 128, 64, 3, 1, false, 8>(a, s);
       return launch_gemm<64, 128, 64, 3, 1>(a, s);
     }
     const long t64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64);

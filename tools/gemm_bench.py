@@ -22,13 +22,12 @@ def build(ablate, extra=""):
 
 def main():
     variants = {"auto": build(0)}
-    def cfg(bm, bn, bk, st):
-        return build(0, f"-DMVP_F_BM={bm} -DMVP_F_BN={bn} -DMVP_F_BK={bk} -DMVP_F_ST={st}")
+    def cfg(bm, bn, bk, st, nw=4):
+        return build(0, f"-DMVP_F_BM={bm} -DMVP_F_BN={bn} -DMVP_F_BK={bk} -DMVP_F_ST={st} -DMVP_F_NW={nw}")
     if "--tiles" in sys.argv:
-        variants["plain_s1"] = build(0, "-DMVP_S1_REGBUF=0")
-        for c in ((128,128,64,1),(64,128,64,1),(128,64,64,1),(64,64,64,1)):
+        for c in ((128,128,64,1,4),(128,128,64,1,8),(256,128,64,1,8),(128,64,64,1,8),(64,128,64,1,4),(64,64,64,1,4),(128,128,64,2,8),(256,128,32,2,8)):
             try:
-                variants["%dx%dk%ds%d" % c] = cfg(*c)
+                variants["%dx%dk%ds%dw%d" % c] = cfg(*c)
             except Exception as e:
                 print("build failed", c)
     if "--ablate" in sys.argv:
