@@ -100,7 +100,8 @@ __device__ __forceinline__ void region_tile(int L, int TM, int TN, int M, int N,
 // (no unit ever waits) sums all S partials in the fixed order 0..S-1 (deterministic whichever unit does it) and
 // runs the normal fused epilogue.  The counter resets itself for the next launch.
 // NW = waves per workgroup (4: 2x2 wave grid; 8: 4x2, i.e. the same tile cut into more, smaller wave tiles).
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT, bool KSPLIT = false, int NW = 4>
+// WNW = waves along N (the wave grid is (NW / WNW) x WNW).
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT, bool KSPLIT = false, int NW = 4, int WNW = 2>
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   static_assert(!(KSPLIT && (CONV || EXT)), "split-K is compiled for the plain linear GEMMs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   constexpr int A_BYTES = BM * ROWB;
   constexpr int W_BYTES = BN * ROWB;
   constexpr int STAGE = (A_BYTES + W_BYTES) * NARR;
-  constexpr int WM = BM / (NW / 2), WN = BN / 2;  // per-wave output tile ((NW/2) x 2 waves)
+  constexpr int WM = BM / (NW / WNW), WN = BN / WNW;  // per-wave output tile
   constexpr int NT_THREADS = NW * 64;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int KS = BK / 32;              // MFMA k-steps per tile
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   region_tile(bid, tiles_m, tiles_n, p.M, p.N, tiles_m * tiles_n > 256 * SLOTS, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WNW) * WM, wn0 = (wave % WNW) * WN;
   const int nk_all = p.K / BK;
   const int kt0 = KSPLIT ? (int)(((long)split * nk_all) / S) : 0;
 #if MVP_ABLATE == 4
@@ -489,22 +490,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   }
 }
 
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE, int NW = 4>
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, int NW = 4, int WNW = 2>
 constexpr int gemm_smem() {
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int stages = NSTAGE * (BM + BN) * BK * 2 * NARR;
-  constexpr int epi = NW * 32 * (BN / 2 + 4) * 4;
+  constexpr int epi = NW * 32 * (BN / WNW + 4) * 4;
   return stages > epi ? stages : epi;
 }
 
-template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV = false, int NW = 4>
+template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV = false, int NW = 4, int WNW = 2>
 int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
-  constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE, NW>();
+  constexpr int SMEM = gemm_smem<BM, BN, BK, SPLIT, NSTAGE, NW, WNW>();
   static_assert(SMEM <= 160 * 1024, "LDS budget");
   static int configured = [] {
-    int e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false, false, NW>,
+    int e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false, false, NW, WNW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW>,
+    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW, WNW>,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     return e;
   }();
@@ -512,9 +513,9 @@ int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res;
   if (ext)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW, WNW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false, false, NW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, false, false, NW, WNW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
@@ -587,8 +588,11 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
 #ifndef MVP_F_NW
 #define MVP_F_NW 4
 #endif
-  return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST, false, MVP_F_NW>(a, s)
-            : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST, false, MVP_F_NW>(a, s);
+#ifndef MVP_F_WNW
+#define MVP_F_WNW 2
+#endif
+  return x3 ? launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 3, MVP_F_ST, false, MVP_F_NW, MVP_F_WNW>(a, s)
+            : launch_gemm<MVP_F_BM, MVP_F_BN, MVP_F_BK, 1, MVP_F_ST, false, MVP_F_NW, MVP_F_WNW>(a, s);
 #else
   // Tile choice, split mode (measured on MI355X, tools/gemm_bench.py --tiles at M = 3152 and M = 12608; us, old -> new):
   //   qkv 41.3 -> 37.2 / 150.8 -> 138.6, proj 21.1 -> 17.2 / 63.7 -> 49.5, fc1 62.7 -> 51.3 / 193.8 -> 180.6,

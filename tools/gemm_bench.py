@@ -22,12 +22,12 @@ def build(ablate, extra=""):
 
 def main():
     variants = {"auto": build(0)}
-    def cfg(bm, bn, bk, st, nw=4):
-        return build(0, f"-DMVP_F_BM={bm} -DMVP_F_BN={bn} -DMVP_F_BK={bk} -DMVP_F_ST={st} -DMVP_F_NW={nw}")
+    def cfg(bm, bn, bk, st, nw=4, wnw=2):
+        return build(0, f"-DMVP_F_BM={bm} -DMVP_F_BN={bn} -DMVP_F_BK={bk} -DMVP_F_ST={st} -DMVP_F_NW={nw} -DMVP_F_WNW={wnw}")
     if "--tiles" in sys.argv:
-        for c in ((128,128,64,1,4),(128,128,64,1,8),(256,128,64,1,8),(128,64,64,1,8),(64,128,64,1,4),(64,64,64,1,4),(128,128,64,2,8),(256,128,32,2,8)):
+        for c in ((64,128,64,1,4,2),(64,128,64,1,8,4),(64,64,64,1,4,2),(64,64,64,1,8,4),(128,64,64,1,8,2),(128,128,64,1,8,4),(128,128,64,1,8,2),(64,256,64,1,8,4)):
             try:
-                variants["%dx%dk%ds%dw%d" % c] = cfg(*c)
+                variants["%dx%dk%ds%dw%dn%d" % c] = cfg(*c)
             except Exception as e:
                 print("build failed", c)
     if "--ablate" in sys.argv:
