@@ -75,26 +75,36 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const mvp_cls_rows_args p
 }
 
 // ----------------------------------------------------------------------------- BN over tokens
-constexpr int BN_RB = 8;   // rows per partial-statistics slab (small slabs -> ~400 workgroups at M ~ 3k)
+constexpr int BN_RB = 8;   // rows per load batch of the partial-statistics pass
 
-// Pass 1: per 32-row slab and channel, shifted sums (shift = first row of the slab) so that
-// the later variance is free of catastrophic cancellation even when |mean| >> std.
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int C) {
-  const int r0 = blockIdx.x * BN_RB;
-  const int nr = min(BN_RB, M - r0);
+// rows per slab: 8 for the ViT taps (M ~ 3k -> ~400 workgroups), growing with M so that the finalize pass folds at
+// most ~2k slabs per channel (ResNet taps have M = 230k rows: 8-row slabs meant 28.8k slabs and a 57 us finalize)
+__host__ __device__ inline int bn_slab_rows(int M) {
+  int rb = BN_RB;
+  while ((M + rb - 1) / rb > 2048) rb <<= 1;
+  return rb;
+}
+
+// Pass 1: per slab and channel, shifted sums (shift = first row of the slab) so that the later variance is free of
+// catastrophic cancellation even when |mean| >> std.
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int C, int rb) {
+  const int r0 = blockIdx.x * rb;
+  const int nr = min(rb, M - r0);
   const int c = blockIdx.y * 256 + threadIdx.x;
   if (c >= C) return;
   const float* col = x + (size_t)r0 * C + c;
-  float v[BN_RB];
-#pragma unroll
-  for (int r = 0; r < BN_RB; ++r) v[r] = col[(size_t)min(r, nr - 1) * C];  // all loads in flight together
-  const float shift = v[0];
+  const float shift = col[0];
   float s1 = 0.f, s2 = 0.f;
+  for (int rr = 0; rr < nr; rr += BN_RB) {
+    float v[BN_RB];
 #pragma unroll
-  for (int r = 0; r < BN_RB; ++r) {
-    const float d = (r < nr) ? v[r] - shift : 0.f;
-    s1 += d;
-    s2 += d * d;
+    for (int r = 0; r < BN_RB; ++r) v[r] = col[(size_t)min(rr + r, nr - 1) * C];  // all loads in flight together
+#pragma unroll
+    for (int r = 0; r < BN_RB; ++r) {
+      const float d = (rr + r < nr) ? v[r] - shift : 0.f;
+      s1 += d;
+      s2 += d * d;
+    }
   }
   float* o = part + ((size_t)blockIdx.x * C + c) * 3;
   o[0] = shift; o[1] = s1; o[2] = s2;
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 constexpr int BN_FC = 16, BN_FG = 64;
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
-                                                           float* __restrict__ ss, int M, int nslab) {
+                                                           float* __restrict__ ss, int M, int nslab, int rb) {
   __shared__ double red[BN_FG][BN_FC][2];
   const int lc = threadIdx.x & (BN_FC - 1), grp = threadIdx.x / BN_FC;
   const int c = blockIdx.x * BN_FC + lc;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_a
       for (int u = 0; u < 4; ++u) {
         const int s = s0 + u * BN_FG;
         if (s < nslab) {
-          const double nb = (double)min(BN_RB, M - s * BN_RB);
+          const double nb = (double)min(rb, M - s * rb);
           const double d = (double)o0[u] - ref, a1 = (double)o1[u], a2 = (double)o2[u];
           // sum (x - ref) and sum (x - ref)^2 of this slab from its own shifted sums
           s1 += a1 + nb * d;
@@ -299,7 +309,8 @@ extern "C" int mvp_cls_rows(const mvp_cls_rows_args* a, void* stream) {
 }
 
 extern "C" int64_t mvp_bn_tokens_workspace_bytes(int M, int C) {
-  const int64_t nslab = (M + BN_RB - 1) / BN_RB;
+  const int rb = bn_slab_rows(M);
+  const int64_t nslab = (M + rb - 1) / rb;
   return (nslab * C * 3 + 2 * (int64_t)C) * 4;
 }
 
@@ -311,12 +322,13 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   if (a->mode == 0 && !a->stats) return MVP_EINVAL;
   if (a->mode == 1 && (!a->running_mean || !a->running_var)) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int nslab = (M + BN_RB - 1) / BN_RB;
+  const int rb = bn_slab_rows(M);
+  const int nslab = (M + rb - 1) / rb;
   float* part = (float*)a->workspace;
   float* ss = part + (size_t)nslab * a->C * 3;
   if (a->mode == 0) {
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab, (a->C + 255) / 256), dim3(256), 0, s, a->x, part, M, a->C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + BN_FC - 1) / BN_FC), dim3(1024), 0, s, *a, part, ss, M, nslab);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab, (a->C + 255) / 256), dim3(256), 0, s, a->x, part, M, a->C, rb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + BN_FC - 1) / BN_FC), dim3(1024), 0, s, *a, part, ss, M, nslab, rb);
   } else {
     hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
   }

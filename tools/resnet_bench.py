@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Diagnostic: ResNet-50 (DINO wrapper, 4 taps, inputs resized to 480x480) frozen-forward throughput + kernel trace."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "midvision-probe_amd"))
+import torch
+from evals.models.dino_res50 import DINO_RESNET
+
+dev = torch.device("cuda")
+B = int(os.environ.get("B", 16))
+m = DINO_RESNET(return_multilayer=True, add_norm=True).to(dev)
+x = torch.randn(B, 3, 224, 224, device=dev)
+for _ in range(3):
+    out = m(x)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n):
+    out = m(x)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"ResNet-50 multilayer extract B={B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} img/s, taps {[tuple(o.shape) for o in out]}")
