@@ -23,7 +23,6 @@
 // SPLIT == 3 runs hi*hi + hi*lo + lo*hi (three MFMAs per tile) on bf16 pairs: operand error
 // ~2^-17 instead of 2^-9, which is what the reference's 1e-3 feature parity needs.
 #include "mvp_common.h"
-#include <cstdlib>
 
 // Diagnostic builds only (tools/gemm_bench.py compiles separate .so files with these set):
 //   MVP_ABLATE 1: no MFMA (fragments read and kept live), 2: no LDS-DMA after the first tile,
@@ -543,10 +542,7 @@ int launch_gemm_splitk(const mvp_gemm_args* a, hipStream_t s) {
 }
 
 // One tile rule for the split-K path (the workspace query must agree with the launch).
-inline bool splitk_wide(int N) {
-  static const int force = getenv("MVP_SPLITK_WIDE") ? atoi(getenv("MVP_SPLITK_WIDE")) : -1;  // diagnostic A/B
-  return force >= 0 ? force != 0 : N >= 1024;
-}
+inline bool splitk_wide(int N) { return N >= 1024; }
 
 }  // namespace
 
