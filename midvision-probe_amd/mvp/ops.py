@@ -78,11 +78,13 @@ _SPLITK_WS = {}  # device -> zero-initialised workspace (tile counters reset the
 
 
 def splitk_auto(M: int, N: int, K: int) -> int:
-    """Split-K factor used when the caller does not give one: always 1.  Measured on MI355X (tools/splitk_bench.py,
-    B=16 hot-path shapes, bf16x3): proj 27.1 us unsplit vs 33.6 (S=2); fc2 71.8 vs 77.3 (S=2) / 86.0 (S=4);
-    head 34.7 vs 33.2 (S=4, within noise).  The N=768 GEMMs are bound by the L2->LDS load path of the bf16-pair
-    operands, not by tile imbalance, so extra workgroups only add the partial-tile round trip.  The kernel path
-    stays available (splitk=S) for shapes with far fewer tiles than CUs."""
+    """Split-K factor used when the caller does not give one.  Measured on MI355X (tools/splitk_bench.py and in-step,
+    bf16x3): the N = 768 projections do NOT profit (proj 27.1 us unsplit vs 33.6 at S=2; fc2 71.8 vs 77.3): they are
+    bound by the L2->LDS operand path, not by tile imbalance.  The one shape that does is the probe head at small M
+    (skinny N <= 256, long K, <= 128 tiles): its A operand was just written by the tap kernels and comes from HBM /
+    Infinity Cache, and 4x more workgroups pull it 4x wider: 52.5 -> 40.4 us inside the step at B=16."""
+    if N <= 256 and K >= 2048 and ((M + 127) // 128) * ((N + 63) // 64) <= 128:
+        return 4
     return 1
 
 
