@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--precision", default=os.environ.get("MVP_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: batches start in host memory and go through mvp.prefetch.DevicePrefetcher (not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-oracle steps (~1.8 s each at B=16 on 16 cores: ~11 s bounded sample)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
