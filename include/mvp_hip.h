@@ -408,7 +408,7 @@ int mvp_linear_bins_bwd(const mvp_linear_bins_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * im2col of an NCHW fp32 image for convs whose Cin is not a multiple of 32 (the ResNet 7x7/2 RGB
- * stem, dino_res50.py:38-44): out[(b,yo,xo), (ky*kw+kx)*C + c], zero padded to ldk columns.
+ * stem, dino_res50.py:38-44): out[(b,yo,xo), (ky*kw+kx)*C + c], zero padded to ldk columns (ldk % 8 == 0).
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const float* src; mvp_bf16* out_hi; mvp_bf16* out_lo;

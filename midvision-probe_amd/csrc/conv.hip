@@ -86,26 +86,36 @@ __global__ __launch_bounds__(256) void upsample_nearest_cl_bwd(const mvp_upsampl
 // ----------------------------------------------------------------------------- im2col (NCHW fp32 image -> GEMM rows)
 // For convs whose Cin is not a multiple of 32 (the 7x7/2 RGB stem): row m = (b, yo, xo),
 // col k = (ky*kw + kx)*C + c, zero padded up to ldk columns.
+// One thread = 8 consecutive k of one output row (one 16-byte store per output array; the per-row index arithmetic is
+// shared by the 8 elements).
 __global__ __launch_bounds__(256) void im2col_nchw_kernel(const mvp_im2col_args p) {
   const int Kc = p.kh * p.kw * p.C;
-  const int64_t total = (int64_t)p.B * p.Ho * p.Wo * p.ldk;
+  const int k8 = p.ldk >> 3;
+  const int64_t total = (int64_t)p.B * p.Ho * p.Wo * k8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int k = (int)(i % p.ldk);
-    const int64_t m = i / p.ldk;
-    float v = 0.f;
-    if (k < Kc) {
-      const int c = k % p.C, t = k / p.C, ky = t / p.kw, kx = t - ky * p.kw;
-      const int xo = (int)(m % p.Wo);
-      const int64_t r = m / p.Wo;
-      const int yo = (int)(r % p.Ho);
-      const int64_t b = r / p.Ho;
-      const int y = yo * p.stride + ky - p.pad, x = xo * p.stride + kx - p.pad;
-      if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) v = p.src[((b * p.C + c) * p.H + y) * p.W + x];
+    const int64_t m = i / k8;
+    const int k0 = (int)(i - m * k8) << 3;
+    const int xo = (int)(m % p.Wo);
+    const int64_t r = m / p.Wo;
+    const int yo = (int)(r % p.Ho);
+    const int64_t b = r / p.Ho;
+    const int ybase = yo * p.stride - p.pad, xbase = xo * p.stride - p.pad;
+    const float* img = p.src + b * p.C * p.H * p.W;
+    uint16_t h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + e;
+      float v = 0.f;
+      if (k < Kc) {
+        const int t = k / p.C, c = k - t * p.C, ky = t / p.kw, kx = t - ky * p.kw;
+        const int y = ybase + ky, x = xbase + kx;
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) v = img[((size_t)c * p.H + y) * p.W + x];
+      }
+      split_bf16(v, h[e], l[e]);
     }
-    uint16_t h, l;
-    split_bf16(v, h, l);
-    p.out_hi[i] = h;
-    if (p.out_lo) p.out_lo[i] = l;
+    const size_t o = (size_t)m * p.ldk + k0;
+    *(u32x4_t*)(p.out_hi + o) = u32x4_t{pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
+    if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])};
   }
 }
 
@@ -360,8 +370,8 @@ extern "C" int mvp_upsample_nearest_cl(const mvp_upsample_cl_args* a, void* stre
 
 extern "C" int mvp_im2col_nchw(const mvp_im2col_args* a, void* stream) {
   if (!a || !a->src || !a->out_hi || a->B <= 0 || a->C <= 0 || a->kh <= 0 || a->kw <= 0 || a->stride <= 0) return MVP_EINVAL;
-  if (a->ldk < a->kh * a->kw * a->C || a->Ho <= 0 || a->Wo <= 0) return MVP_EINVAL;
-  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for((int64_t)a->B * a->Ho * a->Wo * a->ldk, 16384)), dim3(256), 0, (hipStream_t)stream, *a);
+  if (a->ldk < a->kh * a->kw * a->C || (a->ldk & 7) || a->Ho <= 0 || a->Wo <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for((int64_t)a->B * a->Ho * a->Wo * (a->ldk >> 3), 16384)), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

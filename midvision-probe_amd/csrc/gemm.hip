@@ -568,8 +568,13 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     // A K-tile must stay inside one tap: BK = 64 (whole-line rows, single stage: see the tile notes below) when
     // C % 64 == 0, else BK = 32 (any C % 32 == 0), two stages.
     if (x3 && (a->cC & 63) == 0) {
-      if (a->N > 64) return launch_gemm<128, 128, 64, 3, 1, true, 8>(a, s);
-      return launch_gemm<128, 64, 64, 3, 1, true>(a, s);
+      if (a->N <= 64) return launch_gemm<128, 64, 64, 3, 1, true>(a, s);
+      // few-tile, long-K convolutions (ResNet layer3 / layer4 3x3 at 30^2 / 15^2: 226 / 116 tiles of 128x128):
+      // smaller tiles so that every CU holds several workgroups of the single-stage loop
+      const long c128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+      if (c128 >= 300) return launch_gemm<128, 128, 64, 3, 1, true, 8>(a, s);
+      if (c128 >= 160) return launch_gemm<64, 128, 64, 3, 1, true>(a, s);
+      return launch_gemm<64, 64, 64, 3, 1, true>(a, s);
     }
     if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
     return x3 ? launch_gemm<128, 64, 32, 3, 2, true>(a, s) : launch_gemm<128, 64, 32, 1, 2, true>(a, s);
