@@ -46,8 +46,12 @@ struct AttnState {
 
 // One 64-key tile for one wave (32 query rows).  kb / vb: LDS bases of the K and V images of this tile
 // (lo images follow at +TILE when SPLIT == 3).  last: whether keys beyond N must be masked.
-template <int SPLIT>
-__device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, const char* vb, int key0, int N, bool last, float cs, int lane) {
+// The kernels are VALU-bound (per 64-key tile and wave: ~1100 vector instructions against 96 MFMAs), so the softmax
+// body is kept lean: raw v_exp_f32 (__builtin_amdgcn_exp2f: no denormal range fix-up, 5 instructions fewer per
+// element; probabilities below 2^-126 are zero either way) and the key-validity mask compiled only into the LAST
+// tile's instantiation.
+template <int SPLIT, bool LAST>
+__device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, const char* vb, int key0, int N, float cs, int lane) {
   const int g = lane >> 4, c16 = lane & 15;
   f32x4_t s[4][2];
 #pragma unroll
@@ -95,13 +99,13 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (last) s[t][qt][j] = ((kbase + t * 16 + j) < N) ? s[t][qt][j] : -1e30f;
+        if (LAST) s[t][qt][j] = ((kbase + t * 16 + j) < N) ? s[t][qt][j] : -1e30f;
         tmax = fmaxf(tmax, s[t][qt][j]);
       }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(st.m_run[qt], tmax);
-    const float alpha = exp2f((st.m_run[qt] - m_new) * cs);
+    const float alpha = __builtin_amdgcn_exp2f((st.m_run[qt] - m_new) * cs);
     const float mc = m_new * cs;
     st.m_run[qt] = m_new;
     float psum = 0.f;
@@ -109,7 +113,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pv = exp2f(s[t][qt][j] * cs - mc);
+        const float pv = __builtin_amdgcn_exp2f(s[t][qt][j] * cs - mc);
         psum += pv;
         const __bf16 ph = (__bf16)pv;
         p_hi[qt][t >> 1][(t & 1) * 4 + j] = ph;
@@ -237,7 +241,8 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attenti
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     if (active) {
       const char* kb = smem + (kt & 1) * STAGE;
-      attn_tile<SPLIT>(st, kb, kb + NARR * TILE, kt * 64, p.N, kt == nkt - 1, cs, lane);
+      if (kt == nkt - 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+      else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -269,13 +274,17 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
     char* base = smem + kt * STAGE;
     attn_stage_piece<SPLIT>(p, rowbase, h, kt * 64, wave * 8, base, base + NARR * TILE, lane);
   }
-  if (active && MVP_ATT_ABLATE != 5) attn_tile<SPLIT>(st, smem, smem + NARR * TILE, 0, p.N, nkt == 1, cs, lane);
+  if (active && MVP_ATT_ABLATE != 5) {
+    if (nkt == 1) attn_tile<SPLIT, true>(st, smem, smem + NARR * TILE, 0, p.N, cs, lane);
+    else attn_tile<SPLIT, false>(st, smem, smem + NARR * TILE, 0, p.N, cs, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (!active) return;  // no barrier follows
   for (int kt = 1; kt < (MVP_ATT_ABLATE == 5 ? 0 : nkt); ++kt) {
     const char* kb = smem + kt * STAGE;
-    attn_tile<SPLIT>(st, kb, kb + NARR * TILE, kt * 64, p.N, kt == nkt - 1, cs, lane);
+    if (kt == nkt - 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+    else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
   }
   attn_store<SPLIT>(st, p, rowbase, q0, h, lane);
 }
