@@ -128,6 +128,9 @@ typedef struct {
    * splitk_ws: >= mvp_gemm_splitk_workspace_bytes(M, N, splitk) bytes whose leading tile counters are ZERO
    * at first use (they reset themselves); not shared by GEMMs running concurrently on other streams.   */
   int splitk; void* splitk_ws; int64_t splitk_ws_bytes;
+  /* --- optional residual given as a bf16 pair (row stride ldr, elements), added like `residual`:
+   * lets a frozen trunk keep block outputs only as pairs (ResNet identities, dino_res50.py:83-101). */
+  const mvp_bf16* residual_hi; const mvp_bf16* residual_lo;
 } mvp_gemm_args;
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
 int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits);

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   const uint8_t* x_relu_mask = EXT ? p.relu_mask : nullptr;
   uint8_t* x_out_mask = EXT ? p.out_mask : nullptr;
   const float* x_residual2 = EXT ? p.residual2 : nullptr;
+  const mvp_bf16* x_res_hi = EXT ? p.residual_hi : nullptr;
   const int x_act_after = EXT ? p.act_after_res : 0;
   const int x_mask_mode = EXT ? p.mask_mode : 0;
   // Per-wave private scratch [32 rows][WN + 4] fp32; the trailing barrier of the main loop has
@@ -452,6 +453,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
           for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
         }
       }
+      if (x_res_hi) {  // residual kept only as a bf16 pair (ResNet identities: no fp32 copy of every block output)
+        const size_t ro = (size_t)rrow * p.ldr + ncol;
+        if (vec_ok && ((p.ldr & 3) == 0)) {
+          const u32x2_t h2 = *(const u32x2_t*)(x_res_hi + ro);
+          const u32x2_t l2 = p.residual_lo ? *(const u32x2_t*)(p.residual_lo + ro) : u32x2_t{0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t hw = h2[e >> 1], lw = l2[e >> 1];
+            v[e] += __builtin_bit_cast(float, (e & 1) ? (hw & 0xffff0000u) : (hw << 16)) +
+                    __builtin_bit_cast(float, (e & 1) ? (lw & 0xffff0000u) : (lw << 16));
+          }
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < p.N) v[e] += bf2f(x_res_hi[ro + e]) + (p.residual_lo ? bf2f(p.residual_lo[ro + e]) : 0.f);
+        }
+      }
       if (x_residual2) {
         const float* rp = x_residual2 + (size_t)orow * p.ldr + ncol;
         for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
@@ -510,7 +527,7 @@ int launch_gemm(const mvp_gemm_args* a, hipStream_t s) {
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
-  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res;
+  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi;
   if (ext)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, SPLIT, NSTAGE, CONV, true, false, NW, WNW>), dim3(tiles), dim3(NW * 64), SMEM, s, *a);
   else
@@ -579,7 +596,7 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
     return x3 ? launch_gemm<128, 64, 32, 3, 2, true>(a, s) : launch_gemm<128, 64, 32, 1, 2, true>(a, s);
   }
-  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res;
+  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi;
   if (a->splitk > 1 && !ext) {  // (with the ReLU-gate / second-residual epilogues the request is ignored)
     if (a->splitk > 64 || a->K / 64 < a->splitk) return MVP_EINVAL;
     if (splitk_wide(a->N)) return x3 ? launch_gemm_splitk<128, 128, 64, 3, 1>(a, s) : launch_gemm_splitk<128, 128, 64, 1, 2>(a, s);

@@ -50,7 +50,8 @@ class GemmArgs(C.Structure):
                 ("row_group", _i), ("row_group_stride", _i), ("row_group_off", _i), ("res_row_mod", _i),
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
-                ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64)]
+                ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64),
+                ("residual_hi", _vp), ("residual_lo", _vp)]
 
 
 class LayerNormArgs(C.Structure):

@@ -99,8 +99,9 @@ def _splitk_workspace(M: int, N: int, S: int, device) -> torch.Tensor:
 def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, out_f32=None, out: Optional[Pair] = None,
          act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
          row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0,
-         splitk: Optional[int] = None) -> None:
-    """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off."""
+         splitk: Optional[int] = None, residual_pair: Optional[Pair] = None) -> None:
+    """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off.
+    residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``."""
     o_hi, o_lo = out if out is not None else (None, None)
     args = lib.GemmArgs(
         lib.ptr(a[0]), lib.ptr(a[1]), lib.ptr(w[0]), lib.ptr(w[1]), lib.ptr(bias), lib.ptr(residual),
@@ -111,8 +112,10 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     args.act_after_res = int(act_after_res)
     if out_mask is not None:
         args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
+    if residual_pair is not None:
+        args.residual_hi, args.residual_lo = lib.ptr(residual_pair[0]), lib.ptr(residual_pair[1])
     S = 1
-    if out_mask is None and not act_after_res:
+    if out_mask is None and not act_after_res and residual_pair is None:
         S = splitk_auto(M, N, K) if splitk is None else int(splitk)
     if S > 1:
         ws = _splitk_workspace(M, N, S, a[0].device)

@@ -77,7 +77,10 @@ class ResNetEngine:
         lib.call("mvp_maxpool_cl", lib.MaxpoolClArgs(lib.ptr(y), lib.ptr(pf), lib.ptr(pp[0]), lib.ptr(pp[1]), B, Ho, Wo, self.c0, Hp, Wp, 3, 2, 1))
         return pf, pp, Hp, Wp
 
-    def _bottleneck(self, blk: dict, xF, xP, B, H, W):
+    def _bottleneck(self, blk: dict, xP, B, H, W, want_f32: bool):
+        """One bottleneck on channels-last bf16 pairs.  The identity is read back from the block input PAIR (hi + lo,
+        2^-17 relative) — an fp32 copy of every block output would add a third of the HBM traffic of layer1; the fp32
+        map is produced only for the block whose output is tapped (``want_f32``)."""
         pr, dev = self.pr, self.device
         s = blk["stride"]
         Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
@@ -87,13 +90,13 @@ class ResNetEngine:
         o2 = ops.empty_pair((M_out, blk["width"]), pr, dev)
         cv.conv_gemm(o1, cv.geom(B, H, W, blk["width"], 3, 3, s, 1), blk["w2"], blk["width"], bias=blk["b2"], act=lib.ACT_RELU, out=o2, precision=pr)
         if "wd" in blk:
-            idt = torch.empty(M_out, blk["cout"], dtype=torch.float32, device=dev)
-            cv.conv_gemm(xP, cv.geom(B, H, W, blk["cin"], 1, 1, s, 0), blk["wd"], blk["cout"], bias=blk["bd"], out_f32=idt, precision=pr)
+            idt = ops.empty_pair((M_out, blk["cout"]), pr, dev)
+            cv.conv_gemm(xP, cv.geom(B, H, W, blk["cin"], 1, 1, s, 0), blk["wd"], blk["cout"], bias=blk["bd"], out=idt, precision=pr)
         else:
-            idt = xF
-        yF = torch.empty(M_out, blk["cout"], dtype=torch.float32, device=dev)
+            idt = xP
+        yF = torch.empty(M_out, blk["cout"], dtype=torch.float32, device=dev) if want_f32 else None
         yP = ops.empty_pair((M_out, blk["cout"]), pr, dev)
-        ops.gemm(o2, blk["w3"], M_out, blk["cout"], blk["width"], bias=blk["b3"], residual=idt, out_f32=yF, out=yP,
+        ops.gemm(o2, blk["w3"], M_out, blk["cout"], blk["width"], bias=blk["b3"], residual_pair=idt, out_f32=yF, out=yP,
                  act=lib.ACT_RELU, act_after_res=True, precision=pr)
         return yF, yP, Ho, Wo
 
@@ -111,8 +114,9 @@ class ResNetEngine:
         last = max(multilayers)
         for i in range(5):
             if i > 0:
-                for blk in self.blocks[i - 1]:
-                    xF, xP, H, W = self._bottleneck(blk, xF, xP, B, H, W)
+                stage = self.blocks[i - 1]
+                for j, blk in enumerate(stage):
+                    xF, xP, H, W = self._bottleneck(blk, xP, B, H, W, want_f32=(i in multilayers) and j == len(stage) - 1)
             if i in multilayers:
                 C = self.stage_channels[i]
                 HW = H * W
