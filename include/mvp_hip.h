@@ -86,7 +86,7 @@ int mvp_patch_gather(const mvp_patch_gather_args*, void* stream);
 /* ------------------------------------------------------------------------------------
  * GEMM with fused epilogue:   Y = act(A · Wᵀ + bias) + residual
  *   A  [M, K]  bf16 pair, row stride lda;   W  [N, K]  bf16 pair (torch Linear layout),
- *   row stride ldw;  K % 64 == 0;  fp32 accumulation on the bf16 MFMA pipe.
+ *   row stride ldw;  K % 64 == 0 (K % 32 == 0 in bf16x3 mode, without split-K);  fp32 accumulation on the bf16 MFMA pipe.
  * Replaces nn.Linear / 1x1 conv call sites: ibot_transformers.py:124,143 (qkv, proj),
  * :95-106 (fc1+GELU+fc2), :216-222 (patch-embed as GEMM), probes.py:352-355,420-432.
  * Output rows can be remapped (patch-embed writes token rows behind the CLS slot):

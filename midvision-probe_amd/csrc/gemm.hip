@@ -571,7 +571,10 @@ extern "C" int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits) {
 // Diagnostic override (tools/gemm_bench.py): -DMVP_F_BM=.. -DMVP_F_BN=.. -DMVP_F_BK=.. -DMVP_F_ST=..
 extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (!a || !a->a_hi || !a->w_hi) return MVP_EINVAL;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & (a->conv ? 31 : 63))) return MVP_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & (a->conv ? 31 : 63))) {
+    // the one non-conv exception: K % 32 == 0 through the BK = 32 two-stage tile (ResNet stem: K = 147 padded to 160)
+    if (!(a && !a->conv && a->M > 0 && a->N > 0 && a->K > 0 && (a->K & 31) == 0 && a->precision == MVP_PREC_BF16X3 && a->splitk <= 1)) return MVP_EINVAL;
+  }
   if ((a->lda & 7) || (a->ldw & 7)) return MVP_EINVAL;  // 16-byte aligned rows for LDS-DMA
   if (a->precision == MVP_PREC_BF16X3 && (!a->a_lo || !a->w_lo)) return MVP_EINVAL;
   if (a->precision != MVP_PREC_BF16 && a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
@@ -596,6 +599,7 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     if (a->N > 64) return x3 ? launch_gemm<128, 128, 32, 3, 2, true>(a, s) : launch_gemm<128, 128, 32, 1, 2, true>(a, s);
     return x3 ? launch_gemm<128, 64, 32, 3, 2, true>(a, s) : launch_gemm<128, 64, 32, 1, 2, true>(a, s);
   }
+  if (a->K & 63) return launch_gemm<128, 64, 32, 3, 2>(a, s);
   const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi;
   if (a->splitk > 1 && !ext) {  // (with the ReLU-gate / second-residual epilogues the request is ignored)
     if (a->splitk > 64 || a->K / 64 < a->splitk) return MVP_EINVAL;

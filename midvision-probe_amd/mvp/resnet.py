@@ -37,7 +37,7 @@ class ResNetEngine:
         w, b = _fold(sd, "conv1", "bn1")
         self.c0 = w.shape[0]
         wk = w.permute(0, 2, 3, 1).reshape(self.c0, -1)  # k = (ky*7 + kx)*3 + c
-        self.stem_k = 192
+        self.stem_k = 160  # 7*7*3 = 147 padded to a multiple of 32 (BK = 32 tile)
         wpad = wk.new_zeros(self.c0, self.stem_k)
         wpad[:, : wk.shape[1]] = wk
         self.stem_w, self.stem_b = ops.split_bf16(wpad.contiguous(), pr), b
