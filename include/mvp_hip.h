@@ -53,6 +53,7 @@ typedef struct {
 #define MVP_ABI_VERSION 1
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
+int mvp_sizeof(const char* struct_name); /* sizeof(<struct_name>) as compiled into the library, -1 if unknown: for bindings to self-check */
 
 /* ------------------------------------------------------------------------------------
  * Elementwise split:  fp32 [n] -> bf16 pair.  Used once per frozen-weight tensor.

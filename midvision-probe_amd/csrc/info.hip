@@ -21,6 +21,21 @@ extern "C" int mvp_get_info(mvp_info_t* out) {
   return MVP_OK;
 }
 
+// sizeof() of an argument struct by its C name: lets a binding verify its mirror of the header (field order / padding
+// drift between include/mvp_hip.h and a ctypes / JNI / cgo struct is otherwise silent).  -1 = unknown name.
+extern "C" int mvp_sizeof(const char* name) {
+  if (!name) return -1;
+#define MVP_SZ(T) if (strcmp(name, #T) == 0) return (int)sizeof(T);
+  MVP_SZ(mvp_info_t) MVP_SZ(mvp_split_bf16_args) MVP_SZ(mvp_patch_gather_args) MVP_SZ(mvp_gemm_args) MVP_SZ(mvp_layernorm_args)
+  MVP_SZ(mvp_attention_args) MVP_SZ(mvp_cls_rows_args) MVP_SZ(mvp_bn_tokens_args) MVP_SZ(mvp_pack_nchw_args) MVP_SZ(mvp_resize_args)
+  MVP_SZ(mvp_depth_predict_args) MVP_SZ(mvp_depth_loss_args) MVP_SZ(mvp_angular_loss_args) MVP_SZ(mvp_colsum_args) MVP_SZ(mvp_adamw_args)
+  MVP_SZ(mvp_corr_argmax_args) MVP_SZ(mvp_conv_weight_pack_args) MVP_SZ(mvp_upsample_cl_args) MVP_SZ(mvp_gemm_tn_args)
+  MVP_SZ(mvp_depth_metrics_args) MVP_SZ(mvp_snorm_metrics_args) MVP_SZ(mvp_linear_bins_args) MVP_SZ(mvp_im2col_args)
+  MVP_SZ(mvp_maxpool_cl_args) MVP_SZ(mvp_mask_split_args)
+#undef MVP_SZ
+  return -1;
+}
+
 extern "C" const char* mvp_strerror(int code) {
   switch (code) {
     case MVP_OK: return "ok";

@@ -166,6 +166,7 @@ class GemmTnArgs(C.Structure):
 SYMBOLS = {
     "mvp_get_info": None,
     "mvp_strerror": None,
+    "mvp_sizeof": None,
     "mvp_split_bf16": SplitArgs,
     "mvp_patch_gather": PatchGatherArgs,
     "mvp_gemm_bias_act_res": GemmArgs,
@@ -224,6 +225,8 @@ def load() -> C.CDLL:
     lib.mvp_get_info.restype = _i
     lib.mvp_strerror.argtypes = [_i]
     lib.mvp_strerror.restype = C.c_char_p
+    lib.mvp_sizeof.argtypes = [C.c_char_p]
+    lib.mvp_sizeof.restype = _i
     lib.mvp_bn_tokens_workspace_bytes.argtypes = [_i, _i]
     lib.mvp_bn_tokens_workspace_bytes.restype = _i64
     lib.mvp_colsum_workspace_bytes.argtypes = [_i, _i]

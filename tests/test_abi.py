@@ -57,3 +57,29 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(lib.MvpError, match="no CPU fallback"):
         lib.load()
+
+
+def test_ctypes_structs_match_the_compiled_header():
+    """Every ctypes mirror in mvp/lib.py has the size the C compiler gave the struct of include/mvp_hip.h
+    (mvp_sizeof): catches field-order / padding drift between the header and the binding."""
+    from mvp import lib
+
+    so = lib.load()
+    names = {
+        "mvp_info_t": lib.Info, "mvp_split_bf16_args": lib.SplitArgs, "mvp_patch_gather_args": lib.PatchGatherArgs,
+        "mvp_gemm_args": lib.GemmArgs, "mvp_layernorm_args": lib.LayerNormArgs, "mvp_attention_args": lib.AttentionArgs,
+        "mvp_cls_rows_args": lib.ClsRowsArgs, "mvp_bn_tokens_args": lib.BnTokensArgs, "mvp_pack_nchw_args": lib.PackNchwArgs,
+        "mvp_resize_args": lib.ResizeArgs, "mvp_depth_predict_args": lib.DepthPredictArgs, "mvp_depth_loss_args": lib.DepthLossArgs,
+        "mvp_angular_loss_args": lib.AngularLossArgs, "mvp_colsum_args": lib.ColsumArgs, "mvp_adamw_args": lib.AdamWArgs,
+        "mvp_corr_argmax_args": lib.CorrArgmaxArgs, "mvp_conv_weight_pack_args": lib.ConvWeightPackArgs,
+        "mvp_upsample_cl_args": lib.UpsampleClArgs, "mvp_gemm_tn_args": lib.GemmTnArgs, "mvp_depth_metrics_args": lib.DepthMetricsArgs,
+        "mvp_snorm_metrics_args": lib.SnormMetricsArgs, "mvp_linear_bins_args": lib.LinearBinsArgs, "mvp_im2col_args": lib.Im2colArgs,
+        "mvp_maxpool_cl_args": lib.MaxpoolClArgs, "mvp_mask_split_args": lib.MaskSplitArgs,
+    }
+    import re
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "mvp_hip.h")).read()
+    declared = set(re.findall(r"^\} (mvp_\w+);", header, flags=re.M))
+    assert declared == set(names), declared ^ set(names)
+    for cname, cls in names.items():
+        assert so.mvp_sizeof(cname.encode()) == ctypes.sizeof(cls), (cname, so.mvp_sizeof(cname.encode()), ctypes.sizeof(cls))
+    assert so.mvp_sizeof(b"nope") == -1
