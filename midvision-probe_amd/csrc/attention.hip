@@ -53,6 +53,9 @@ struct AttnState {
 template <int SPLIT, bool LAST>
 __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, const char* vb, int key0, int N, float cs, int lane) {
   const int g = lane >> 4, c16 = lane & 15;
+  // LAST tile: only the first nsub 16-key sub-tiles hold real keys (N = 197: 5 keys of the 4th tile -> nsub = 1); the
+  // products of the all-padding sub-tiles are skipped (wave-uniform branches) and their probabilities set to zero.
+  const int nsub = LAST ? min(4, (N - key0 + 15) >> 4) : 4;
   f32x4_t s[4][2];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -63,6 +66,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
     const int coff = (((ks << 2) + g) ^ (lane & 7)) << 4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+      if (LAST && t >= nsub) continue;
       const char* ka = kb + (t * 16 + c16) * 128 + coff;
       const bf16x8_t k_hi = *(const bf16x8_t*)ka;
       if (SPLIT == 3) {
@@ -113,7 +117,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float pv = __builtin_amdgcn_exp2f(s[t][qt][j] * cs - mc);
+        const float pv = (LAST && t >= nsub) ? 0.f : __builtin_amdgcn_exp2f(s[t][qt][j] * cs - mc);
         psum += pv;
         const __bf16 ph = (__bf16)pv;
         p_hi[qt][t >> 1][(t & 1) * 4 + j] = ph;
@@ -127,6 +131,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
   const int tr_q = c16 >> 2, tr_p = lane & 3;
 #pragma unroll
   for (int ks = 0; ks < (MVP_ATT_ABLATE == 2 ? 0 : 2); ++ks) {
+    if (LAST && 2 * ks >= nsub) continue;    // both 16-key sub-tiles of this half are padding (P = 0)
     const int row = ks * 32 + g * 4 + tr_q;  // +16 for the second read
     const int fsw = ((row >> 1) & 3) << 1;   // identical for row and row + 16
 #pragma unroll
