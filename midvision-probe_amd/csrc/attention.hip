@@ -192,11 +192,11 @@ __device__ __forceinline__ void attn_store(AttnState<SPLIT>& st, const mvp_atten
     const size_t ob = (rowbase + qrow) * p.ld_out + h * 64 + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      uint16_t hh[4], ll[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) split_bf16(st.o_acc[dt][qt][j] * inv, hh[j], ll[j]);
-      *(u32x2_t*)(p.out_hi + ob + dt * 16) = u32x2_t{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
-      if (p.out_lo) *(u32x2_t*)(p.out_lo + ob + dt * 16) = u32x2_t{pack2(ll[0], ll[1]), pack2(ll[2], ll[3])};
+      uint32_t h01, l01, h23, l23;
+      split2_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
+      split2_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
+      *(u32x2_t*)(p.out_hi + ob + dt * 16) = u32x2_t{h01, h23};
+      if (p.out_lo) *(u32x2_t*)(p.out_lo + ob + dt * 16) = u32x2_t{l01, l23};
     }
   }
 }

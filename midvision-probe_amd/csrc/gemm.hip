@@ -487,14 +487,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
         }
       }
       if (p.out_hi) {
-        uint16_t hh[4], ll[4];
+        if (x_mask_mode == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split_bf16((x_mask_mode == 1) ? v[e] * keep[e] : v[e], hh[e], ll[e]);
+          for (int e = 0; e < 4; ++e) v[e] *= keep[e];  // (out_f32 above stayed un-gated)
+        }
+        uint32_t h01, l01, h23, l23;
+        split2_bf16(v[0], v[1], h01, l01);
+        split2_bf16(v[2], v[3], h23, l23);
         const size_t o = (size_t)orow * p.ldob + ncol;
         if (vec_ok && ((p.ldob & 3) == 0)) {
-          *(u32x2_t*)(p.out_hi + o) = u32x2_t{pack2(hh[0], hh[1]), pack2(hh[2], hh[3])};
-          if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{pack2(ll[0], ll[1]), pack2(ll[2], ll[3])};
+          *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
+          if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{l01, l23};
         } else {
+          const uint16_t hh[4] = {(uint16_t)h01, (uint16_t)(h01 >> 16), (uint16_t)h23, (uint16_t)(h23 >> 16)};
+          const uint16_t ll[4] = {(uint16_t)l01, (uint16_t)(l01 >> 16), (uint16_t)l23, (uint16_t)(l23 >> 16)};
           for (int e = 0; e < 4; ++e)
             if (ncol + e < p.N) {
               p.out_hi[o + e] = hh[e];

@@ -56,11 +56,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
         y[h * 4 + 3] = (v[i][h].w - mean) * rstd * g.w + b.w;
       }
       const size_t o = (size_t)row * p.C + c * 8;
-      uint16_t h[8], l[8];
+      uint32_t h[4], l[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) split_bf16(y[e], h[e], l[e]);
-      *(u32x4_t*)(p.out_hi + o) = u32x4_t{pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
-      if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])};
+      for (int e = 0; e < 4; ++e) split2_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
+      *(u32x4_t*)(p.out_hi + o) = u32x4_t{h[0], h[1], h[2], h[3]};
+      if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{l[0], l[1], l[2], l[3]};
       if (p.out_f32) {
         *(float4*)(p.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
         *(float4*)(p.out_f32 + o + 4) = make_float4(y[4], y[5], y[6], y[7]);

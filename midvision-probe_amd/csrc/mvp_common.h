@@ -28,6 +28,16 @@ __device__ __forceinline__ void split_bf16(float v, uint16_t& hi, uint16_t& lo) 
   hi = f2bf(v);
   lo = f2bf(v - bf2f(hi));
 }
+// Two values at once, already packed (low half = a): one v_cvt_pk_bf16_f32 per array and no re-packing — 14 vector
+// instructions per 4 elements instead of 21 through split_bf16 + pack2 (same roundings, bit-identical results).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const bf16x2_t h = {(__bf16)a, (__bf16)b};
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  const bf16x2_t l = {(__bf16)(a - ha), (__bf16)(b - hb)};
+  lo = __builtin_bit_cast(uint32_t, l);
+}
 __device__ __forceinline__ uint32_t pack2(uint16_t a, uint16_t b) {
   return (uint32_t)a | ((uint32_t)b << 16);
 }
