@@ -328,9 +328,10 @@ typedef struct {
   const float* src_feat; const float* tgt_feat; /* [C, h, w] fp32 each            */
   const float* kp_xy;                            /* [K,2] normalised coords in [-1,1] (x,y) */
   int64_t* out_xy; float* out_val;
-  float* workspace; int64_t workspace_bytes;    /* >= (2*h*w + K*C) * 4            */
+  float* workspace; int64_t workspace_bytes;    /* >= mvp_corr_workspace_bytes(C, h, w, K), 8-byte aligned */
   int C, h, w, K;
 } mvp_corr_argmax_args;
+int64_t mvp_corr_workspace_bytes(int C, int h, int w, int K);
 int mvp_corr_argmax(const mvp_corr_argmax_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -14,14 +14,21 @@ __global__ __launch_bounds__(256) void corr_norm_kernel(const mvp_corr_argmax_ar
   if (i >= 2 * hw) return;
   const float* f = (i < hw) ? p.src_feat + i : p.tgt_feat + (i - hw);
   float s = 0.f;
-  for (int c = 0; c < p.C; ++c) { const float v = f[(size_t)c * hw]; s += v * v; }
+  int c = 0;
+  for (; c + 8 <= p.C; c += 8) {  // 8 channel loads in flight; summation order unchanged
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = f[(size_t)(c + u) * hw];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u] * v[u];
+  }
+  for (; c < p.C; ++c) { const float v = f[(size_t)c * hw]; s += v * v; }
   inv[i] = 1.0f / fmaxf(sqrtf(s), 1e-12f);  // F.normalize eps
 }
 
-// one block per keypoint
-__global__ __launch_bounds__(256) void corr_kernel(const mvp_corr_argmax_args p, const float* inv, float* desc_all) {
-  __shared__ float best_v[256];
-  __shared__ int best_i[256];
+// descriptors: one block per keypoint, desc[k][c] = bilinear sample of the normalised source map; also resets the
+// keypoint's running (value, index) key.
+__global__ __launch_bounds__(256) void corr_desc_kernel(const mvp_corr_argmax_args p, const float* inv, float* desc_all, unsigned long long* keys) {
   const int k = blockIdx.x, hw = p.h * p.w;
   float* desc = desc_all + (size_t)k * p.C;
   // grid_sample bilinear, align_corners=True, padding zeros
@@ -41,49 +48,90 @@ __global__ __launch_bounds__(256) void corr_kernel(const mvp_corr_argmax_args p,
       }
     desc[c] = acc;
   }
+  if (threadIdx.x == 0) keys[k] = 0ull;
+}
+
+// (value, index) packed so that an unsigned 64-bit max = "largest value, smallest index among ties" (torch.argmax keeps
+// the first maximum); max is order-independent, so the atomic keeps the result deterministic.
+__device__ __forceinline__ unsigned long long corr_key(float v, int idx) {
+  const unsigned b = __builtin_bit_cast(unsigned, v);
+  const unsigned ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+  return ((unsigned long long)ord << 32) | (unsigned long long)(0xffffffffu - (unsigned)idx);
+}
+
+// heat map + argmax: grid (pixel chunks of 256, K).  Lanes run along the pixels (coalesced reads of the [C, hw] target map),
+// the descriptor sits in LDS, 8 channel loads in flight per thread.  (One block per keypoint with a serial channel loop
+// took 1.78 ms at 50x50x768; this form runs on K * hw / 256 workgroups.)
+__global__ __launch_bounds__(256) void corr_heat_kernel(const mvp_corr_argmax_args p, const float* inv, const float* desc_all, unsigned long long* keys) {
+  extern __shared__ float desc[];
+  __shared__ unsigned long long best[4];
+  const int k = blockIdx.y, hw = p.h * p.w;
+  for (int c = threadIdx.x; c < p.C; c += 256) desc[c] = desc_all[(size_t)k * p.C + c];
   __syncthreads();
-  float bv = -INFINITY;
-  int bi = 0x7fffffff;
-  for (int pix = threadIdx.x; pix < hw; pix += 256) {
-    float acc = 0.f;
-    for (int c = 0; c < p.C; ++c) acc += desc[c] * p.tgt_feat[(size_t)c * hw + pix];
-    acc *= inv[hw + pix];
-    if (acc > bv) { bv = acc; bi = pix; }  // strided visit order is increasing: first max kept
-  }
-  best_v[threadIdx.x] = bv;
-  best_i[threadIdx.x] = bi;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float ov = best_v[threadIdx.x + s];
-      const int oi = best_i[threadIdx.x + s];
-      if (ov > best_v[threadIdx.x] || (ov == best_v[threadIdx.x] && oi < best_i[threadIdx.x])) {
-        best_v[threadIdx.x] = ov;
-        best_i[threadIdx.x] = oi;
-      }
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long key = 0ull;
+  if (pix < hw) {
+    const float* t = p.tgt_feat + pix;
+    float acc = 0.f;  // same channel order as a serial loop: bit-identical to the previous kernel
+    int c = 0;
+    for (; c + 8 <= p.C; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = t[(size_t)(c + u) * hw];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += desc[c + u] * v[u];
     }
-    __syncthreads();
+    for (; c < p.C; ++c) acc += desc[c] * t[(size_t)c * hw];
+    acc *= inv[hw + pix];
+    key = corr_key(acc, pix);
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(key >> 32), o, 64) << 32) | (unsigned long long)__shfl_xor((unsigned)key, o, 64);
+    key = other > key ? other : key;
+  }
+  if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = key;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const int idx = best_i[0];
-    p.out_xy[k * 2] = idx % p.w;      // col
-    p.out_xy[k * 2 + 1] = idx / p.w;  // row
-    if (p.out_val) p.out_val[k] = best_v[0];
+    unsigned long long m = best[0];
+    for (int i = 1; i < 4; ++i) m = best[i] > m ? best[i] : m;
+    atomicMax(keys + k, m);
   }
+}
+
+__global__ void corr_final_kernel(const mvp_corr_argmax_args p, const unsigned long long* keys) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= p.K) return;
+  const unsigned long long key = keys[k];
+  const int idx = (int)(0xffffffffu - (unsigned)(key & 0xffffffffull));
+  const unsigned ord = (unsigned)(key >> 32);
+  const unsigned b = (ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord;
+  p.out_xy[k * 2] = idx % p.w;      // col
+  p.out_xy[k * 2 + 1] = idx / p.w;  // row
+  if (p.out_val) p.out_val[k] = __builtin_bit_cast(float, b);
 }
 
 }  // namespace
 
+extern "C" int64_t mvp_corr_workspace_bytes(int C, int h, int w, int K) {
+  if (C <= 0 || h <= 0 || w <= 0 || K <= 0) return 0;
+  // inverse norms (2hw) + descriptors (K*C), then K 64-bit keys on an 8-byte boundary
+  return ((((int64_t)2 * h * w + (int64_t)K * C) * 4 + 7) & ~(int64_t)7) + (int64_t)K * 8;
+}
+
 extern "C" int mvp_corr_argmax(const mvp_corr_argmax_args* a, void* stream) {
   if (!a || !a->src_feat || !a->tgt_feat || !a->kp_xy || !a->out_xy || !a->workspace) return MVP_EINVAL;
-  if (a->C <= 0 || a->h <= 0 || a->w <= 0 || a->K <= 0) return MVP_EINVAL;
-  const int64_t need = ((int64_t)2 * a->h * a->w + (int64_t)a->K * a->C) * 4;
-  if (a->workspace_bytes < need) return MVP_EINVAL;
+  if (a->C <= 0 || a->h <= 0 || a->w <= 0 || a->K <= 0 || a->C > 16384) return MVP_EINVAL;
+  if (a->workspace_bytes < mvp_corr_workspace_bytes(a->C, a->h, a->w, a->K) || ((uintptr_t)a->workspace & 7)) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const int hw = a->h * a->w;
   float* inv = a->workspace;
-  float* desc = inv + 2 * a->h * a->w;
-  hipLaunchKernelGGL(corr_norm_kernel, dim3((2 * a->h * a->w + 255) / 256), dim3(256), 0, s, *a, inv);
-  hipLaunchKernelGGL(corr_kernel, dim3(a->K), dim3(256), 0, s, *a, inv, desc);
+  float* desc = inv + 2 * hw;
+  unsigned long long* keys = (unsigned long long*)((char*)a->workspace + ((((int64_t)2 * hw + (int64_t)a->K * a->C) * 4 + 7) & ~(int64_t)7));
+  hipLaunchKernelGGL(corr_norm_kernel, dim3((2 * hw + 255) / 256), dim3(256), 0, s, *a, inv);
+  hipLaunchKernelGGL(corr_desc_kernel, dim3(a->K), dim3(256), 0, s, *a, inv, desc, keys);
+  hipLaunchKernelGGL(corr_heat_kernel, dim3((hw + 255) / 256, a->K), dim3(256), a->C * sizeof(float), s, *a, inv, desc, keys);
+  hipLaunchKernelGGL(corr_final_kernel, dim3((a->K + 63) / 64), dim3(64), 0, s, *a, keys);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

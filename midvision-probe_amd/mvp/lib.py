@@ -188,6 +188,7 @@ SYMBOLS = {
     "mvp_colsum": ColsumArgs,
     "mvp_adamw_step": AdamWArgs,
     "mvp_corr_argmax": CorrArgmaxArgs,
+    "mvp_corr_workspace_bytes": None,
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
     "mvp_mask_split": MaskSplitArgs,
@@ -225,6 +226,8 @@ def load() -> C.CDLL:
     lib.mvp_get_info.restype = _i
     lib.mvp_strerror.argtypes = [_i]
     lib.mvp_strerror.restype = C.c_char_p
+    lib.mvp_corr_workspace_bytes.argtypes = [_i, _i, _i, _i]
+    lib.mvp_corr_workspace_bytes.restype = _i64
     lib.mvp_sizeof.argtypes = [C.c_char_p]
     lib.mvp_sizeof.restype = _i
     lib.mvp_bn_tokens_workspace_bytes.argtypes = [_i, _i]

@@ -22,7 +22,7 @@ def correspondence(feats_i: torch.Tensor, feats_j: torch.Tensor, kps_i_xy01: tor
     ndc = (kps_i_xy01.to(dev, torch.float32) * 2 - 1).contiguous()
     out_xy = torch.empty(K, 2, dtype=torch.int64, device=dev)
     out_val = torch.empty(K, dtype=torch.float32, device=dev)
-    ws = torch.empty(2 * h * w + K * C + 16, dtype=torch.float32, device=dev)
+    ws = torch.empty((int(lib.load().mvp_corr_workspace_bytes(C, h, w, K)) + 3) // 4, dtype=torch.float32, device=dev)
     ops.corr_argmax(feats_i.contiguous().float(), feats_j.contiguous().float(), ndc, out_xy, out_val, ws, C, h, w, K)
     return out_xy, out_val
 
