@@ -3,7 +3,7 @@
 operand is rounded to a 16-bit format (fp32 accumulate)?  Decides which MFMA operand formats can meet the
 1e-3 rel tolerance.  Uses the oracle as the fp32 model; nothing here is on the product path."""
 import os, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 import torch, torch.nn.functional as F
 from oracle import vit as ov

@@ -10,7 +10,7 @@ evals/models/probes.py, evals/utils/losses.py, evals/utils/optim.py — behind s
 ``evals`` / ``evals.models`` / ``evals.utils`` packages because the shipped
 ``evals/models/__init__.py`` re-exports names that no longer exist.
 
-    python tools/make_goldens.py            # writes tests/golden/*.npz
+    python tests/golden/make_goldens.py            # writes tests/golden/*.npz
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ import types
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = os.environ.get("MVP_REFERENCE", "/root/reference")
 OUT = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)

@@ -113,7 +113,7 @@ class _MaskedRelu(torch.autograd.Function):
 def _dpt_fp64_with_masks(sd, feats, ctx, B, h, w):
     """fp64 restatement of probes.py:377-399 (transformer variant) whose ReLU gates are taken from
     the HIP forward.  A 1e-5-accurate forward flips ~1e-5 of the masks of a 16-conv ReLU stack, which
-    alone moves parameter gradients by sqrt(1e-5) ~ 3e-3 rel-L2 (measured, tools/debug_dpt*.py);
+    alone moves parameter gradients by sqrt(1e-5) ~ 3e-3 rel-L2 (measured stage by stage against an fp64 restatement);
     with the gates pinned, the hand-written backward chain must agree to rounding."""
     from mvp import dpt as mdpt
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 # different branch under a different (equally valid) fp32 evaluation order — the reference
 # upsamples 3072 channels then convolves, we convolve then upsample.  A fraction f ~ 3e-6 of
 # flipped mask elements gives a rel-L2 difference of sqrt(f) ~ 2e-3 (measured: 1.9e-3 in
-# d loss/d logits with every other stage of the chain matching to 1e-6, tools/debug_head.py).
+# d loss/d logits with every other stage of the chain matching to 1e-6).
 # So gradients are held to 5e-3 rel-L2 AND 1 - cosine < 2e-5.
 GRAD_TOL = 5e-3
 

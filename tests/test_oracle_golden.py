@@ -1,5 +1,5 @@
 """Pin the CPU oracle to the golden vectors produced by the reference's own modules
-(tools/make_goldens.py).  CPU only; these run with -m "not gpu"."""
+(tests/golden/make_goldens.py).  CPU only; these run with -m "not gpu"."""
 import numpy as np
 import pytest
 import torch
