@@ -7,7 +7,7 @@ import torch
 from mvp import lib, ops, conv
 
 dev = torch.device("cuda")
-for (B, H, C, Co) in ((16, 28, 256, 256), (16, 56, 256, 256), (16, 112, 256, 128)):
+for (B, H, C, Co) in ((16, 28, 512, 512), (8, 64, 512, 512), (16, 56, 256, 256), (8, 128, 512, 256), (16, 112, 256, 128)):
     M = B * H * H
     x = ops.split_bf16(torch.randn(M, C, device=dev), 3); g = ops.split_bf16(torch.randn(M, max(Co, 128), device=dev) * 1e-2, 3)
     geo = conv.geom(B, H, H, C, 3, 3, 1, 1)
