@@ -68,16 +68,33 @@ __global__ __launch_bounds__(256) void depth_sigmoid_bwd(const mvp_depth_predict
 
 // Column sums, deterministic two-level reduction: level 1 = (64-column strip) x (row chunk)
 // workgroups write partial sums into the workspace, level 2 adds the chunks in a fixed order.
-constexpr int CS_CHUNK = 64;  // rows per level-1 workgroup
+constexpr int CS_CHUNK = 64;  // minimum rows per level-1 workgroup
 
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const mvp_colsum_args p, float* part) {
+// rows per level-1 chunk: 64 at ViT sizes, growing with M so that level 2 folds at most 256 chunks per column (the DPT
+// bias gradients have M = 131k..524k rows: 2048+ chunks made the second level a 30 us serial sum)
+__host__ __device__ inline int cs_chunk_rows(int M) {
+  const int r = (M + 255) / 256;
+  return r < CS_CHUNK ? CS_CHUNK : ((r + 3) & ~3);
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const mvp_colsum_args p, float* part, int chunk) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * CS_CHUNK, r1 = min(p.M, r0 + CS_CHUNK);
+  const int r0 = blockIdx.y * chunk, r1 = min(p.M, r0 + chunk);
   float s = 0.f;
-  if (c < p.N)
-    for (int r = r0 + rg; r < r1; r += 4) s += p.x[(size_t)r * p.ld + c];
+  if (c < p.N) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 loads in flight; fixed combination order
+    int r = r0 + rg;
+    for (; r + 12 < r1; r += 16) {
+      s0 += p.x[(size_t)r * p.ld + c];
+      s1 += p.x[(size_t)(r + 4) * p.ld + c];
+      s2 += p.x[(size_t)(r + 8) * p.ld + c];
+      s3 += p.x[(size_t)(r + 12) * p.ld + c];
+    }
+    for (; r < r1; r += 4) s0 += p.x[(size_t)r * p.ld + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[rg][threadIdx.x & 63] = s;
   __syncthreads();
   if (rg == 0 && c < p.N)
@@ -145,15 +162,17 @@ extern "C" int mvp_depth_predict_bwd(const mvp_depth_predict_args* a, void* stre
 }
 
 extern "C" int64_t mvp_colsum_workspace_bytes(int M, int N) {
-  return (int64_t)((M + CS_CHUNK - 1) / CS_CHUNK) * N * 4;
+  const int chunk = cs_chunk_rows(M);
+  return (int64_t)((M + chunk - 1) / chunk) * N * 4;
 }
 
 extern "C" int mvp_colsum(const mvp_colsum_args* a, void* stream) {
   if (!a || !a->x || !a->out || !a->workspace || a->M <= 0 || a->N <= 0 || a->ld < a->N) return MVP_EINVAL;
   if (a->workspace_bytes < mvp_colsum_workspace_bytes(a->M, a->N)) return MVP_EINVAL;
-  const int nchunk = (a->M + CS_CHUNK - 1) / CS_CHUNK;
+  const int chunk = cs_chunk_rows(a->M);
+  const int nchunk = (a->M + chunk - 1) / chunk;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((a->N + 63) / 64, nchunk), dim3(256), 0, s, *a, (float*)a->workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((a->N + 63) / 64, nchunk), dim3(256), 0, s, *a, (float*)a->workspace, chunk);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((a->N + 63) / 64), dim3(256), 0, s, *a, (const float*)a->workspace, nchunk);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
@@ -180,13 +199,47 @@ __global__ __launch_bounds__(256) void mask_split_kernel(const mvp_mask_split_ar
     if (p.dst_lo) p.dst_lo[i] = l;
   }
 }
+
+// 4 columns per thread (N, ldo, lds, ldm all multiples of 4): float4 / 4-byte mask loads, 16-byte and 8-byte stores.
+__global__ __launch_bounds__(256) void mask_split_vec4_kernel(const mvp_mask_split_args p) {
+  const int q = p.ldo >> 2;
+  const int64_t total = (int64_t)p.M * q;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) << 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < p.N) {
+      v = *(const float4*)(p.src + r * p.lds + c);
+      if (p.mask) {
+        const uint32_t m = *(const uint32_t*)(p.mask + r * p.ldm + c);
+        if (!(m & 0xffu)) v.x = 0.f;
+        if (!(m & 0xff00u)) v.y = 0.f;
+        if (!(m & 0xff0000u)) v.z = 0.f;
+        if (!(m & 0xff000000u)) v.w = 0.f;
+      }
+      if (p.dst_f32) *(float4*)(p.dst_f32 + r * p.lds + c) = v;
+    }
+    uint32_t h01, l01, h23, l23;
+    split2_bf16(v.x, v.y, h01, l01);
+    split2_bf16(v.z, v.w, h23, l23);
+    const int64_t o = r * p.ldo + c;
+    if (p.dst_hi) *(u32x2_t*)(p.dst_hi + o) = u32x2_t{h01, h23};
+    if (p.dst_lo) *(u32x2_t*)(p.dst_lo + o) = u32x2_t{l01, l23};
+  }
+}
 }  // namespace
 
 extern "C" int mvp_mask_split(const mvp_mask_split_args* a, void* stream) {
   if (!a || !a->src || a->M <= 0 || a->N <= 0 || a->ldo < a->N || a->lds < a->N) return MVP_EINVAL;
-  int64_t g = ((int64_t)a->M * a->ldo + 255) / 256;
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(mask_split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *a);
+  const bool vec = !((a->N | a->ldo | a->lds) & 3) && (!a->mask || !(a->ldm & 3)) &&
+                   !(((uintptr_t)a->src | (uintptr_t)a->dst_f32) & 15) && !(((uintptr_t)a->dst_hi | (uintptr_t)a->dst_lo) & 7) &&
+                   !((uintptr_t)a->mask & 3);
+  int64_t g = ((int64_t)a->M * (vec ? a->ldo >> 2 : a->ldo) + 255) / 256;
+  if (g > 16384) g = 16384;
+  if (vec)
+    hipLaunchKernelGGL(mask_split_vec4_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(mask_split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
