@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libmvp_hip.so (built artefacts are git-ignored): build it once (hipcc cross-compiles gfx950
+    without a GPU) so that the ABI tests can load it.  An existing library is left alone."""
+    so = os.path.join(PKG, "csrc", "libmvp_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc")], check=False, stdout=subprocess.DEVNULL)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
