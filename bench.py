@@ -86,14 +86,37 @@ def flops_per_image(N: int, D: int = 768, depth: int = 12, head_out: int = 256, 
     return float(vit + head)
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh ranks (one per GPU) as children of this
+    process BEFORE it has made any GPU call (importing torch does not initialise HIP), and return their exit code.
+    Mirrors the reference's self-launch (mp.spawn over world_size, train_depth.py:851-855)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     warnings.simplefilter("ignore")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     from mvp import dist as mdist
 
     rank, local, world = mdist.env_setup("nccl")
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a job of a different size")
+    backend = torch.distributed.get_backend() if world > 1 else "none"
+    if world > 1:
+        assert torch.distributed.get_world_size() == args.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", torch.cuda.current_device())
     if "x" in args.image_size:
@@ -121,7 +144,9 @@ def main():
     else:
         probe = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=512,
                           min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
-    opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}])
+    # N > 1: rank 0's probe is broadcast at construction (DDP semantics); the flat-gradient all-reduce of step t runs
+    # under the frozen forward of step t+1 and its AdamW update lands right before the probe forward
+    opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}], overlap_comm=world > 1)
     total_steps = args.warmup + args.steps + 8
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 10 * total_steps, 1.5 * total_steps))
     loss_fn = DepthLoss()
@@ -142,6 +167,7 @@ def main():
         return train_depth_step(model, probe, opt, sched, loss_fn, images, target)
 
     def barrier():
+        opt.finish_pending()  # the last step's update belongs to the timed region
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -261,7 +287,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "images/sec feature-extract+probe-step, ViT-B/16 224^2" if (H, W) == (224, 224) else f"images/sec feature-extract+probe-step, ViT-B/16 {H}x{W}",
-            "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0,
+            "dist_backend": backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/LN/softmax/loss)" if args.precision == "bf16x3" else "bf16 (MFMA, fp32 accumulate)",
             "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",

@@ -1,6 +1,6 @@
 """Minimal stand-in for the slice of hydra the trainers use (hydra / omegaconf are not installed):
-compose ``configs/<name>.yaml`` with its ``defaults`` list (group choices come from ``configs/<group>.yaml`` or, as in
-the reference, from ``configs/<group>/<choice>.yaml``), apply ``group=choice``, ``key.sub=value`` and
+compose ``configs/<name>.yaml`` with its ``defaults`` list (group choices are ``configs/<group>/<choice>.yaml``, the
+reference's hydra layout, so real hydra composes the same tree: ``backbone=dino_b16``), apply ``group=choice``, ``key.sub=value`` and
 ``+key.sub=value`` overrides (README.md:82 style), and ``instantiate`` a ``_target_`` dict
 (configs/backbone/dino_b16.yaml:1, train_depth.py:564-567)."""
 from __future__ import annotations
@@ -41,14 +41,11 @@ def compose(config_name: str, overrides: List[str] = (), config_dir: str = CONFI
             plain.append((key.lstrip("+"), yaml.load(val, Loader=yaml.SafeLoader)))
     cfg = {}
     for group, choice in groups.items():
-        per_file = os.path.join(config_dir, group, f"{choice}.yaml")  # the reference's one-file-per-choice layout still works
-        if os.path.exists(per_file):
-            cfg[group] = _load(per_file)
-            continue
-        table = _load(os.path.join(config_dir, group + ".yaml"))
-        if choice not in table:
-            raise KeyError(f"{group}={choice}: not in {group}.yaml (choices: {sorted(table)})")
-        cfg[group] = dict(table[choice])
+        per_file = os.path.join(config_dir, group, f"{choice}.yaml")
+        if not os.path.exists(per_file):
+            have = sorted(f[:-5] for f in os.listdir(os.path.join(config_dir, group)) if f.endswith(".yaml"))
+            raise KeyError(f"{group}={choice}: no {per_file} (choices: {have})")
+        cfg[group] = _load(per_file)
     cfg.update(root)
     for key, val in plain:
         _set(cfg, key, val)

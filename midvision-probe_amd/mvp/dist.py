@@ -35,6 +35,10 @@ def env_setup(backend: str = "nccl"):
     return rank, local, world
 
 
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
 def all_reduce_sum_flat(flat: torch.Tensor, group=None) -> int:
     """The ONE data-path collective of a training step: SUM over ranks of the flat fp32 probe
     gradient (RCCL over xGMI on GPUs, gloo in the CPU tests).  Returns the world size; the caller

@@ -17,7 +17,13 @@ from . import ops
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, process_group=None, world_size: Optional[int] = None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, process_group=None,
+                 overlap_comm: bool = False, broadcast_init: bool = True):
+        """``overlap_comm``: start the flat-gradient all-reduce asynchronously in ``step()`` (on a copy of the gradient, so
+        ``zero_grad`` may run at once) and apply AdamW in ``finish_pending()`` — the trainers call that right before the next
+        probe forward, so the collective runs under the next step's frozen backbone forward (which does not read the probe
+        weights).  The reference overlaps the same exchange with backward through DDP buckets (train_depth.py:620-622).
+        ``broadcast_init``: rank 0's parameters are broadcast at construction, as the DDP wrap does."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:
@@ -46,7 +52,15 @@ class FlatAdamW(torch.optim.Optimizer):
         self._n = total
         self._step = 0
         self.process_group = process_group
-        self.world_size = world_size
+        self.overlap_comm = bool(overlap_comm)
+        self._pending = None  # (work handle | None, world, lr, step) of a started-but-unapplied update
+        self._comm_buf = None
+        from .dist import world_size as _world
+
+        if broadcast_init and _world(process_group) > 1:
+            import torch.distributed as dist
+
+            dist.broadcast(self.flat_param, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
 
     def zero_grad(self, set_to_none: bool = False):
         """Zero the flat gradient IN PLACE (the .grad views must survive: autograd accumulates into them)."""
@@ -76,16 +90,49 @@ class FlatAdamW(torch.optim.Optimizer):
 
         return all_reduce_sum_flat(self.flat_grad, self.process_group)
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        self._gather_stray_grads()
-        world = self.all_reduce_grads()
+    def _apply(self, grad: torch.Tensor, world: int, lr: float, step: int):
         g = self.param_groups[0]
-        self._step += 1
         b1, b2 = g["betas"]
         # schedule state goes BY VALUE with the launch: a pinned staging buffer would be overwritten by a host that
         # runs several steps ahead of the stream before the earlier async copy has read it
-        ops.adamw_step(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, None, self._n,
+        ops.adamw_step(self.flat_param, grad, self.exp_avg, self.exp_avg_sq, None, self._n,
                        beta1=b1, beta2=b2, eps=g["eps"], weight_decay=g["weight_decay"], grad_scale=1.0 / world,
-                       lr=float(g["lr"]), bias_c1=1.0 - b1 ** self._step, bias_c2=1.0 - b2 ** self._step)
+                       lr=lr, bias_c1=1.0 - b1 ** step, bias_c2=1.0 - b2 ** step)
+
+    @torch.no_grad()
+    def finish_pending(self):
+        """Wait (stream-side) for the in-flight gradient all-reduce and apply the AdamW update it belongs to.
+        No-op when nothing is pending.  Called by the trainers before the probe forward, by ``state_dict`` and by ``step``."""
+        if self._pending is None:
+            return
+        work, world, lr, step = self._pending
+        self._pending = None
+        if work is not None:
+            work.wait()  # nccl: the current stream waits for the collective; gloo: host wait
+        self._apply(self._comm_buf, world, lr, step)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.finish_pending()
+        self._gather_stray_grads()
+        self._step += 1
+        lr = float(self.param_groups[0]["lr"])
+        from .dist import world_size as _world
+
+        world = _world(self.process_group)
+        if self.overlap_comm and world > 1:
+            import torch.distributed as dist
+
+            if self._comm_buf is None:
+                self._comm_buf = torch.empty_like(self.flat_grad)
+            self._comm_buf.copy_(self.flat_grad)
+            work = dist.all_reduce(self._comm_buf, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._pending = (work, world, lr, self._step)
+            return None
+        world = self.all_reduce_grads()
+        self._apply(self.flat_grad, world, lr, self._step)
         return None
+
+    def state_dict(self):
+        self.finish_pending()
+        return super().state_dict()

@@ -20,8 +20,18 @@ def extract_features(model, images, detach_model=True):
             else:
                 feats = feats.detach()
     else:
-        feats = model(images)
+        # every head Function returns None for the feature gradient and the backbone engines run under no_grad: a
+        # trainable backbone (optimizer.model_lr != 0, train_depth.py:566-575) would silently train nothing
+        raise NotImplementedError("detach_model=False (backbone fine-tuning, optimizer.model_lr != 0) is outside the frozen-backbone hot path")
     return feats
+
+
+def _finish_pending(optimizer):
+    """FlatAdamW(overlap_comm=True): the previous step's gradient all-reduce has been running under this step's frozen
+    forward; its AdamW update must land before the probe reads its weights."""
+    fin = getattr(optimizer, "finish_pending", None)
+    if fin is not None:
+        fin()
 
 
 def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model=True):
@@ -29,6 +39,7 @@ def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target
     reference's per-step ``loss.item()`` host sync is left to the caller)."""
     optimizer.zero_grad()
     feats = extract_features(model, images, detach_model)
+    _finish_pending(optimizer)
     pred = probe(feats)
     pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
     loss = loss_fn(pred, target)
@@ -45,6 +56,7 @@ def train_snorm_step(model, probe, optimizer, scheduler, images, target, mask, d
 
     optimizer.zero_grad()
     feats = extract_features(model, images, detach_model)
+    _finish_pending(optimizer)
     pred = probe(feats)
     pred = MF.interpolate(pred.contiguous(), size=target.shape[-2:], mode="bicubic")
     uncertainty = pred.shape[1] > 3

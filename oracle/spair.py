@@ -1,18 +1,19 @@
 """Oracle: SPair-71k correspondence core, fp32 CPU.  Test infrastructure only.
 
 compute_errors, evaluate_spair_correspondence.py:45-103 (feature part) and argmax_2d,
-evals/utils/correspondence.py:179-190 (restated: that module imports faiss at the top and
-cannot be imported here)."""
+evals/utils/correspondence.py:179-190 (restated; the golden fixture comes from the reference module imported behind a faiss stub)."""
 from __future__ import annotations
 
 import torch
 import torch.nn.functional as F
 
 
-def argmax_2d(x: torch.Tensor) -> torch.Tensor:
-    """correspondence.py:179-190 — flat argmax over the last two dims, returned as (col, row)."""
+def argmax_2d(x: torch.Tensor, max_value: bool = True) -> torch.Tensor:
+    """correspondence.py:179-190 — flat argmax (argmin when max_value=False) over the last two dims, returned as (col, row).
+    Pinned bit-exactly by tests/golden/spair.npz (outputs of the reference function, incl. ties)."""
     h, w = x.shape[-2:]
-    flat = torch.flatten(x, start_dim=-2).argmax(dim=-1)
+    flat = torch.flatten(x, start_dim=-2)
+    flat = flat.argmax(dim=-1) if max_value else flat.argmin(dim=-1)
     return torch.stack((flat % w, flat // w), dim=-1)
 
 

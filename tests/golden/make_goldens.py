@@ -346,11 +346,124 @@ def golden_metrics():
     print("metrics", {k: v.shape for k, v in out.items() if k.startswith("sa_")})
 
 
+def _stub_loguru():
+    lg = types.ModuleType("loguru")
+
+    class _L:
+        def warning(self, *a, **k):
+            pass
+
+        info = warning
+
+    lg.logger = _L()
+    sys.modules.setdefault("loguru", lg)
+
+
+def _seg_rows(seg_metrics):
+    return np.array([[m["segment_id"], m["image_idx"], m["area"], m["d1_ratio"]] for m in seg_metrics], dtype=np.float64)
+
+
+def golden_metrics_breakdown():
+    """G7b: the per-level ("centroid level"), stuff/things and per-segment parts of evaluate_depth (metrics.py:179-358) and
+    evaluate_surface_norm (metrics.py:441-577) on a synthetic INTEGER segmentation map (OneFormer ADE20K ids 0..149; 11, 17, 40
+    and 68 are neither STUFF nor THINGS in evals/utils/oneformer_id2label.py).  Two geometries: H divisible by num_levels and
+    not; one image without any valid pixel; one segment id that only occurs on invalid pixels."""
+    _stub_loguru()
+    mt = importlib.import_module("evals.utils.metrics")
+    out = {}
+    for tag, (B, H, W), seed in (("a", (3, 40, 50), 410), ("b", (2, 37, 31), 411)):
+        g = torch.Generator().manual_seed(seed)
+        pr = torch.rand(B, 1, H, W, generator=g) * 9 + 0.05
+        gt = pr * (1 + 0.35 * torch.randn(B, 1, H, W, generator=g)).clamp(min=0.2)  # d1 ~ 0.5: both sides of every threshold
+        gt[torch.rand(gt.shape, generator=g) < 0.2] = 0
+        ids = torch.tensor([0, 3, 5, 7, 8, 11, 17, 26, 40, 68, 100, 128, 149])
+        seg = ids[torch.randint(0, len(ids), (B, H // 4 + 1, W // 4 + 1), generator=g)]
+        seg = seg.repeat_interleave(4, 1).repeat_interleave(4, 2)[:, :H, :W].contiguous()  # 4x4 blobs
+        gt[:, 0][seg == 17] = 0        # id 17 only on invalid pixels: still listed by torch.unique
+        if tag == "a":
+            gt[2] = 0                  # an image without valid pixels
+        sn = torch.randn(B, 4, H, W, generator=g)
+        sg = torch.randn(B, 3, H, W, generator=g)
+        sg = sg / sg.norm(dim=1, keepdim=True)
+        sn[:, :3] = sn[:, :3] * 0.6 + sg * 1.2                       # errors spread around the 11.25/22.5/30 degree thresholds
+        sg[:, :, :5] = 0
+        out[f"{tag}_pred"], out[f"{tag}_gt"], out[f"{tag}_seg"] = _np(pr), _np(gt), _np(seg).astype(np.int32)
+        out[f"{tag}_sn_pred"], out[f"{tag}_sn_gt"] = _np(sn), _np(sg)
+        for mode, si in (("sa", False), ("si", True)):
+            gm, lv, sm = mt.evaluate_depth(pr, gt, seg, scale_invariant=si, is_navi=False)
+            for k, v in gm.items():
+                out[f"{tag}_{mode}_{k}"] = _np(v.reshape(B))
+            for L, d in lv.items():
+                for k, v in d.items():
+                    out[f"{tag}_{mode}_{L}_{k}"] = _np(v.reshape(B))
+            out[f"{tag}_{mode}_segments"] = _seg_rows(sm)
+        gm, lv, sm = mt.evaluate_depth(pr, gt, seg, image_average=True, num_levels=3, is_navi=False)
+        out[f"{tag}_avg3_rmse"] = _np(gm["rmse"])
+        for L, d in lv.items():
+            out[f"{tag}_avg3_{L}_d1"] = _np(d["d1"])
+        gm, lv, sm = mt.evaluate_surface_norm(sn, sg, seg, is_navi=False)
+        for k, v in gm.items():
+            out[f"{tag}_sn_{k}"] = _np(v.reshape(B))
+        for L, d in lv.items():
+            for k, v in d.items():
+                out[f"{tag}_sn_{L}_{k}"] = _np(v.reshape(B))
+        out[f"{tag}_sn_segments"] = _seg_rows(sm)
+    np.savez_compressed(os.path.join(OUT, "metrics_seg.npz"), **out)
+    print("metrics_seg", len(out), "arrays;", {k: v.shape for k, v in out.items() if k.startswith("a_sa_level_1")})
+
+
+def golden_spair():
+    """G8: argmax_2d (evals/utils/correspondence.py:179-190) from the reference module itself.  Its top-level
+    ``import faiss`` / ``faiss.contrib.torch_utils`` / ``faiss.StandardGpuResources()`` (correspondence.py:4-5,11) are
+    satisfied by an empty stub (faiss is not installed; argmax_2d does not use it).  Heat-maps are built the way
+    compute_errors does (evaluate_spair_correspondence.py:59-83: torch core ops + einops) and include exact ties."""
+    fs = types.ModuleType("faiss")
+    fs.StandardGpuResources = lambda: None
+    fc = types.ModuleType("faiss.contrib")
+    ft = types.ModuleType("faiss.contrib.torch_utils")
+    fs.contrib, fc.torch_utils = fc, ft
+    for n, m in (("faiss", fs), ("faiss.contrib", fc), ("faiss.contrib.torch_utils", ft)):
+        sys.modules.setdefault(n, m)
+    co = importlib.import_module("evals.utils.correspondence")
+    import torch.nn.functional as F
+    from einops import einsum
+
+    out = {}
+    g = torch.Generator().manual_seed(500)
+    C, h, w, K = 96, 13, 17, 11                               # non-square map: (col,row) order matters
+    feats = torch.randn(2, C, h, w, generator=g)
+    kps = torch.rand(K, 2, generator=g)
+    kps[0] = torch.tensor([0.0, 0.0]); kps[1] = torch.tensor([1.0, 1.0])
+    kps[2] = torch.tensor([5 / (w - 1), 7 / (h - 1)])          # exactly on source pixel (5, 7)
+    # exact ties: the target carries the descriptor of keypoint 2 at two pixels (rows 3 and 9): argmax must take the first
+    fn = F.normalize(feats, p=2, dim=1)
+    feats[1] *= 0.05
+    feats[1][:, 9, 4] = fn[0][:, 7, 5] * 3.0
+    feats[1][:, 3, 12] = fn[0][:, 7, 5] * 3.0
+    fn = F.normalize(feats, p=2, dim=1)
+    ndc = (kps * 2 - 1)[None, None]
+    kf = F.grid_sample(fn[0][None], ndc, mode="bilinear", align_corners=True)[0, :, 0].t()
+    heat = einsum(kf, fn[1], "k f, f h w -> k h w")
+    out["feats"], out["kps01"], out["heat"] = _np(feats), _np(kps), _np(heat)
+    out["pred_max"] = _np(co.argmax_2d(heat, max_value=True))
+    out["pred_min"] = _np(co.argmax_2d(heat, max_value=False))
+    # integer-valued maps with many ties (plateaus), incl. a constant map and maxima in the last row / column
+    ti = torch.randint(-3, 4, (9, 6, 10), generator=g).float()
+    ti[0] = 2.0
+    ti[1] = -1.0; ti[1, 5, 9] = 7.0
+    ti[2] = 1.0; ti[2, 0, 0] = -7.0
+    out["tie_heat"] = _np(ti)
+    out["tie_max"] = _np(co.argmax_2d(ti, max_value=True))
+    out["tie_min"] = _np(co.argmax_2d(ti, max_value=False))
+    np.savez_compressed(os.path.join(OUT, "spair.npz"), **out)
+    print("spair", out["pred_max"][:4].tolist(), out["tie_max"][:3].tolist(), out["tie_min"][:3].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     vt, pr, ls, op = _load_reference()
-    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics"]
+    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics", "metrics_seg", "spair"]
     if "vit_tiny" in which:
         golden_vit_tiny(vt)
     if "vit_tiny128" in which:
@@ -367,6 +480,10 @@ def main():
         golden_vit_base(vt)
     if "metrics" in which:
         golden_metrics()
+    if "metrics_seg" in which:
+        golden_metrics_breakdown()
+    if "spair" in which:
+        golden_spair()
 
 
 if __name__ == "__main__":
