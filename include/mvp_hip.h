@@ -50,7 +50,7 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 1
+#define MVP_ABI_VERSION 2
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
 int mvp_sizeof(const char* struct_name); /* sizeof(<struct_name>) as compiled into the library, -1 if unknown: for bindings to self-check */
@@ -242,6 +242,9 @@ typedef struct {
 } mvp_resize_args;
 int mvp_resize_fwd(const mvp_resize_args*, void* stream);
 int mvp_resize_bwd(const mvp_resize_args*, void* stream); /* src = grad_out [.,Ho,Wo], dst = grad_in [.,Hi,Wi] */
+/* Antialiased bilinear, forward only, planar, align_corners = 0, sizes given (torchvision transforms.Resize on a tensor =
+ * interpolate(bilinear, antialias=True), dino_res50.py:80,85 for inputs larger than fixed_size on an axis). */
+int mvp_resize_aa_fwd(const mvp_resize_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Depth predictors on token-major logits [P, K] (P = B*H*W pixels, K channels contiguous).
@@ -330,9 +333,16 @@ typedef struct {
   int64_t* out_xy; float* out_val;
   float* workspace; int64_t workspace_bytes;    /* >= mvp_corr_workspace_bytes(C, h, w, K), 8-byte aligned */
   int C, h, w, K;
+  float* heat_out;                               /* optional [K, h, w]: the cosine heat-maps (compute_errors(return_heatmaps=True)) */
 } mvp_corr_argmax_args;
 int64_t mvp_corr_workspace_bytes(int C, int h, int w, int K);
 int mvp_corr_argmax(const mvp_corr_argmax_args*, void* stream);
+/* argmax_2d (evals/utils/correspondence.py:179-190) on materialised maps x [K, h, w] fp32: out_xy [K,2] int64 = (col,row) of
+ * the flat argmax (max_value != 0) or argmin (max_value == 0); ties -> lowest flat index, as torch. */
+typedef struct {
+  const float* x; int64_t* out_xy; int K, h, w, max_value;
+} mvp_argmax_2d_args;
+int mvp_argmax_2d(const mvp_argmax_2d_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution weight re-layout (per step; the probe's conv weights are trained):
@@ -394,6 +404,39 @@ typedef struct {
 int64_t mvp_metrics_workspace_bytes(int B);
 int mvp_depth_metrics(const mvp_depth_metrics_args*, void* stream);
 int mvp_snorm_metrics(const mvp_snorm_metrics_args*, void* stream);
+/* y = x * scale[b] + shift[b] per image (match_scale_and_shift, metrics.py:775-777), optionally clamped to [lo, hi]
+ * (scale-invariant training, train_depth.py:116-118).  backward != 0: out = d/dx = grad_out * scale[b] where the clamp
+ * is inactive, else 0 (scale/shift are detached in the reference).  x / out / grad_out [B, HW]; scale_shift [B, 2]. */
+typedef struct {
+  const float* x; const float* scale_shift; const float* grad_out; float* out;
+  int B; int64_t HW; float lo, hi; int clamp; int backward;
+} mvp_scale_shift_args;
+int mvp_scale_shift(const mvp_scale_shift_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-level / per-segment breakdown of the validation metrics (evaluate_depth
+ * evals/utils/metrics.py:179-358, evaluate_surface_norm metrics.py:441-577) as one segmented masked
+ * reduction per batch.  Every pixel is binned by its "centroid level" (nested centre boxes whose
+ * offset (H / L) * (L - level) / 2 is applied to both axes, metrics.py:249-262) and by its
+ * integer segment id:
+ *   level_sums [B, L, 5] fp64 = {n_valid, #(x<t1), #(x<t2), #(x<t3), sum err^2}
+ *   seg_sums   [B, S, 6] fp64 = {n_all, n_valid, #(x<t1), #(x<t2), #(x<t3), sum err^2}   (ids outside [0,S) are skipped)
+ * Cp == 0: depth — pred/gt [B,H,W], valid = gt > 0, x = max(gt/pred, pred/gt) with thresholds 1.25^k,
+ *          err = gt - pred; scale_shift != NULL applies the per-image (scale, shift) of mvp_depth_metrics first.
+ * Cp >= 3: surface normals — pred [B,Cp,H,W], gt [B,3,H,W], valid = |gt|_1 > 0, x = err = angular error in degrees,
+ *          thresholds t1..t3.
+ * seg == NULL: levels only (the reference's is_navi=True path).  The 1e-6 / clamp(1) normalisations, the
+ * stuff/things grouping and the segment list are finished by the host from these bins.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* pred; const float* gt; const int32_t* seg; const float* scale_shift;
+  double* level_sums; double* seg_sums;
+  void* workspace; int64_t workspace_bytes;   /* >= mvp_metrics_breakdown_workspace_bytes(B, L, S), 8-byte aligned */
+  int B, H, W, Cp, num_levels, num_ids;
+  float t1, t2, t3;
+} mvp_metrics_breakdown_args;
+int64_t mvp_metrics_breakdown_workspace_bytes(int B, int num_levels, int num_ids);
+int mvp_metrics_breakdown(const mvp_metrics_breakdown_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused tail of the linear depth-bin probe: bilinear x f (align_corners=False) of the
@@ -435,10 +478,13 @@ int mvp_maxpool_cl(const mvp_maxpool_cl_args*, void* stream);
  * Gradient gate + split: dst = src * (mask != 0) as fp32 (may alias src) and as a bf16 pair
  * with row stride ldo >= N (pad columns zeroed) — the ReLU backward of probes.py:283-288 fused
  * with the operand conversion for the next MFMA GEMM.  mask may be NULL (plain split).
+ * relu_mask_out != NULL: forward ReLU instead — dst = max(src, 0), relu_mask_out[r*ldm + c] = (src > 0)
+ * (the ReLU that follows a bilinear upsample in MultiscaleHead, probes.py:449-457, fused with the split).
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const float* src; const uint8_t* mask; float* dst_f32; mvp_bf16* dst_hi; mvp_bf16* dst_lo;
   int64_t M; int N, lds, ldm, ldo;
+  uint8_t* relu_mask_out;
 } mvp_mask_split_args;
 int mvp_mask_split(const mvp_mask_split_args*, void* stream);
 

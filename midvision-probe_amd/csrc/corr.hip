@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void corr_heat_kernel(const mvp_corr_argmax_ar
     }
     for (; c < p.C; ++c) acc += desc[c] * t[(size_t)c * hw];
     acc *= inv[hw + pix];
+    if (p.heat_out) p.heat_out[(size_t)k * hw + pix] = acc;
     key = corr_key(acc, pix);
   }
 #pragma unroll
@@ -111,7 +112,42 @@ __global__ void corr_final_kernel(const mvp_corr_argmax_args p, const unsigned l
   if (p.out_val) p.out_val[k] = __builtin_bit_cast(float, b);
 }
 
+// argmax_2d (correspondence.py:179-190) on materialised maps x [K, h, w]: one workgroup per map, (value, index) keys so that
+// ties resolve to the lowest flat index exactly as torch.argmax / torch.argmin do; max_value == 0 orders by -value.
+__global__ __launch_bounds__(256) void argmax2d_kernel(const mvp_argmax_2d_args p) {
+  __shared__ unsigned long long best[4];
+  const int k = blockIdx.x, hw = p.h * p.w;
+  const float* x = p.x + (size_t)k * hw;
+  unsigned long long key = 0ull;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    const float v = x[i];
+    const unsigned long long c = corr_key(p.max_value ? v : -v, i);
+    key = c > key ? c : key;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = ((unsigned long long)__shfl_xor((unsigned)(key >> 32), o, 64) << 32) | (unsigned long long)__shfl_xor((unsigned)key, o, 64);
+    key = other > key ? other : key;
+  }
+  if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long m = best[0];
+    for (int i = 1; i < 4; ++i) m = best[i] > m ? best[i] : m;
+    const int idx = (int)(0xffffffffu - (unsigned)(m & 0xffffffffull));
+    p.out_xy[k * 2] = idx % p.w;
+    p.out_xy[k * 2 + 1] = idx / p.w;
+  }
+}
+
 }  // namespace
+
+extern "C" int mvp_argmax_2d(const mvp_argmax_2d_args* a, void* stream) {
+  if (!a || !a->x || !a->out_xy || a->K <= 0 || a->h <= 0 || a->w <= 0 || (int64_t)a->h * a->w > 0x7fffffff) return MVP_EINVAL;
+  hipLaunchKernelGGL(argmax2d_kernel, dim3(a->K), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
 
 extern "C" int64_t mvp_corr_workspace_bytes(int C, int h, int w, int K) {
   if (C <= 0 || h <= 0 || w <= 0 || K <= 0) return 0;

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void mask_split_kernel(const mvp_mask_split_ar
     if (c < p.N) {
       v = p.src[r * p.lds + c];
       if (p.mask && !p.mask[r * p.ldm + c]) v = 0.f;
+      if (p.relu_mask_out) { const bool on = v > 0.f; v = on ? v : 0.f; p.relu_mask_out[r * p.ldm + c] = on; }
       if (p.dst_f32) p.dst_f32[r * p.lds + c] = v;
     }
     uint16_t h, l;
@@ -217,6 +218,11 @@ __global__ __launch_bounds__(256) void mask_split_vec4_kernel(const mvp_mask_spl
         if (!(m & 0xff0000u)) v.z = 0.f;
         if (!(m & 0xff000000u)) v.w = 0.f;
       }
+      if (p.relu_mask_out) {
+        const uint32_t m = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 0x100u : 0u) | (v.z > 0.f ? 0x10000u : 0u) | (v.w > 0.f ? 0x1000000u : 0u);
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        *(uint32_t*)(p.relu_mask_out + r * p.ldm + c) = m;
+      }
       if (p.dst_f32) *(float4*)(p.dst_f32 + r * p.lds + c) = v;
     }
     uint32_t h01, l01, h23, l23;
@@ -231,9 +237,9 @@ __global__ __launch_bounds__(256) void mask_split_vec4_kernel(const mvp_mask_spl
 
 extern "C" int mvp_mask_split(const mvp_mask_split_args* a, void* stream) {
   if (!a || !a->src || a->M <= 0 || a->N <= 0 || a->ldo < a->N || a->lds < a->N) return MVP_EINVAL;
-  const bool vec = !((a->N | a->ldo | a->lds) & 3) && (!a->mask || !(a->ldm & 3)) &&
+  const bool vec = !((a->N | a->ldo | a->lds) & 3) && ((!a->mask && !a->relu_mask_out) || !(a->ldm & 3)) &&
                    !(((uintptr_t)a->src | (uintptr_t)a->dst_f32) & 15) && !(((uintptr_t)a->dst_hi | (uintptr_t)a->dst_lo) & 7) &&
-                   !((uintptr_t)a->mask & 3);
+                   !(((uintptr_t)a->mask | (uintptr_t)a->relu_mask_out) & 3);
   int64_t g = ((int64_t)a->M * (vec ? a->ldo >> 2 : a->ldo) + 255) / 256;
   if (g > 16384) g = 16384;
   if (vec)

@@ -335,7 +335,54 @@ void launch_bwd(const mvp_resize_args* a, hipStream_t s) {
   }
 }
 
+// Antialiased bilinear resampling, forward only (torchvision transforms.Resize on a tensor = F.interpolate(bilinear,
+// align_corners=False, antialias=True): dino_res50.py:80,85 when an input axis is LARGER than fixed_size).  ATen's
+// _upsample_bilinear2d_aa: per axis, scale = in/out, support = max(scale, 1), the triangle filter is stretched by the
+// scale and its taps renormalised; an axis that up-samples or keeps its size reduces to plain bilinear / identity.
+struct AaAxis { int lo, n; float center, inv, total; };
+__device__ __forceinline__ float aa_w(const AaAxis& a, int j) {
+  const float x = fabsf(((float)(j + a.lo) - a.center + 0.5f) * a.inv);
+  return x < 1.f ? 1.f - x : 0.f;
+}
+__device__ __forceinline__ AaAxis aa_axis(int o, int in, float scale) {
+  AaAxis a;
+  const float support = scale >= 1.f ? scale : 1.f;
+  a.center = scale * ((float)o + 0.5f);
+  a.inv = scale >= 1.f ? 1.f / scale : 1.f;
+  a.lo = max((int)(a.center - support + 0.5f), 0);
+  a.n = min((int)(a.center + support + 0.5f), in) - a.lo;
+  a.total = 0.f;
+  for (int j = 0; j < a.n; ++j) a.total += aa_w(a, j);
+  return a;
+}
+__global__ __launch_bounds__(256) void resize_aa_fwd_planar(const mvp_resize_args p) {
+  const int64_t total = (int64_t)p.planes * p.Ho * p.Wo;
+  const float sh = (float)p.Hi / (float)p.Ho, sw = (float)p.Wi / (float)p.Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int xo = (int)(i % p.Wo), yo = (int)((i / p.Wo) % p.Ho);
+    const int64_t pl = i / ((int64_t)p.Wo * p.Ho);
+    const AaAxis ay = aa_axis(yo, p.Hi, sh), ax = aa_axis(xo, p.Wi, sw);
+    const float* src = p.src + pl * p.Hi * p.Wi;
+    float acc = 0.f;
+    for (int jy = 0; jy < ay.n; ++jy) {
+      const float* row = src + (int64_t)(ay.lo + jy) * p.Wi + ax.lo;
+      float r = 0.f;  // horizontal pass first, as ATen's separable kernel
+      for (int jx = 0; jx < ax.n; ++jx) r += (aa_w(ax, jx) / ax.total) * row[jx];
+      acc += (aa_w(ay, jy) / ay.total) * r;
+    }
+    p.dst[i] = acc;
+  }
+}
+
 }  // namespace
+
+extern "C" int mvp_resize_aa_fwd(const mvp_resize_args* a, void* stream) {
+  if (int e = validate(a)) return e;
+  if (a->mode != MVP_RESIZE_BILINEAR || a->channels_last || a->align_corners || a->scale_h != 0.f || a->scale_w != 0.f) return MVP_EINVAL;
+  hipLaunchKernelGGL(resize_aa_fwd_planar, dim3(grid_for((int64_t)a->planes * a->Ho * a->Wo)), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
 
 extern "C" int mvp_resize_fwd(const mvp_resize_args* a, void* stream) {
   if (int e = validate(a)) return e;

@@ -1,6 +1,6 @@
 """NYU-shaped synthetic dataset honouring the reference's per-sample dict contract (evals/datasets/nyu.py:245-251):
 {"image": float32 [3,H,W] (ImageNet-normalised statistics), "depth": float32 [1,H,W] metres with 0 = invalid,
- "snorm": float32 [3,H,W] unit vectors}.  Samples are a pure function of (seed, split, index), so every rank and every
+ "snorm": float32 [3,H,W] unit vectors, "segmentation": int64 [H,W] OneFormer ADE20K ids in 16x16 blobs}.  Samples are a pure function of (seed, split, index), so every rank and every
 epoch sees the same sample for the same index — what DistributedSampler sharding assumes."""
 from __future__ import annotations
 
@@ -30,4 +30,6 @@ class SyntheticNYU(Dataset):
         if self.with_snorm:
             n = torch.randn(3, H, W, generator=g)
             out["snorm"] = n / n.norm(dim=0, keepdim=True).clamp_min(1e-6)
+        blobs = torch.randint(0, 150, ((H + 15) // 16, (W + 15) // 16), generator=g)
+        out["segmentation"] = blobs.repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W].contiguous()
         return out

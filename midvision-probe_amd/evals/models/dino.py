@@ -50,5 +50,8 @@ class DINO(bb.ViTBackbone):
         self.set_precision(precision or bb.default_precision())
 
     def forward(self, images):
+        if len(self.multilayers) == 1 and self.return_cls:
+            # dino.py:206-207: embeds[0][:, 0] — the (tap-BN normalised when add_norm) CLS token of the single tap
+            return self._extract(images, want_cls=True).cls[0]
         taps = self._extract(images)
         return self._finish(taps)

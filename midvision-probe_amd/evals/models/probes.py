@@ -37,7 +37,7 @@ class SurfaceNormalHead(nn.Module):
         elif head_type == "dpt":
             self.head = DPT(feat_dim, output_dim, hidden_dim, kernel_size, precision=precision)
         else:
-            raise NotImplementedError("multiscale head is not on the hot path (configs/probe use dpt / linear)")
+            self.head = MultiscaleHead(feat_dim, output_dim, hidden_dim, kernel_size, precision=precision)
 
     def forward(self, feats):
         return self.head(feats)
@@ -64,7 +64,7 @@ class DepthHead(nn.Module):
         elif head_type == "dpt":
             self.head = DPT(feat_dim, output_dim, hidden_dim, kernel_size, precision=precision)
         else:
-            raise NotImplementedError("multiscale head is not on the hot path (configs/probe use dpt / linear)")
+            self.head = MultiscaleHead(feat_dim, output_dim, hidden_dim, kernel_size, precision=precision)
 
     def forward(self, feats):
         """Prediction each pixel."""
@@ -142,9 +142,50 @@ class Linear(nn.Module):
         return lq[..., :K].permute(0, 3, 1, 2)  # NCHW view of the channels-last logits
 
 
+def make_conv(input_dim, hidden_dim, output_dim, num_layers, kernel_size=1):
+    """Reference: probes.py:400-412 (parameter containers; note: no padding)."""
+    if num_layers == 1:
+        return nn.Conv2d(input_dim, output_dim, kernel_size)
+    assert num_layers > 1
+    modules = [nn.Conv2d(input_dim, hidden_dim, kernel_size), nn.ReLU(inplace=True)]
+    for _ in range(num_layers - 2):
+        modules += [nn.Conv2d(hidden_dim, hidden_dim, kernel_size), nn.ReLU(inplace=True)]
+    modules.append(nn.Conv2d(hidden_dim, output_dim, kernel_size))
+    return nn.Sequential(*modules)
+
+
+class MultiscaleHead(nn.Module):
+    """Reference: probes.py:435-458 (DepthHead's / SurfaceNormalHead's default head_type).  kernel_size 1 (the default) runs on the
+    HIP path (mvp/multiscale.py); the reference's un-padded k > 1 variant shrinks every map and is not built."""
+
+    def __init__(self, input_dims, output_dim, hidden_dim=512, kernel_size=1, precision=None):
+        super().__init__()
+        input_dims = [d if isinstance(d, int) else d[0] for d in input_dims]
+        self.convs = nn.ModuleList([make_conv(in_d, None, hidden_dim, 1, kernel_size) for in_d in input_dims])
+        interm_dim = len(input_dims) * hidden_dim
+        self.conv_mid = make_conv(interm_dim, hidden_dim, hidden_dim, 3, kernel_size)
+        self.conv_out = make_conv(hidden_dim, hidden_dim, output_dim, 2, kernel_size)
+        self.kernel_size, self.input_dims = kernel_size, input_dims
+        self.precision = _precision(precision)
+
+    def forward(self, feats):
+        from mvp import multiscale as ms
+
+        if self.kernel_size != 1:
+            raise NotImplementedError("MultiscaleHead with kernel_size > 1 (un-padded convs, probes.py:400-412) is not on the HIP path")
+        feats = list(feats)
+        h, w = feats[-1].shape[-2:]
+        # bilinear resample to the last map's size (probes.py:449); it commutes with the 1x1 conv that precedes it in the reference
+        feats = [f if tuple(f.shape[-2:]) == (h, w) else MF.interpolate(f, size=(h, w), mode="bilinear") for f in feats]
+        pack = MF.pack_features(feats, self.precision)
+        lq = ms.multiscale_logits(pack, self.input_dims, self, self.precision)
+        K = self.conv_out[2].out_channels
+        return lq[..., :K].permute(0, 3, 1, 2)
+
+
 class DPT(nn.Module):
-    """Reference: probes.py:309-399.  Transformer variant (4 equal-resolution taps) runs on the HIP
-    conv path (mvp/dpt.py); the ResNet-pyramid variant keeps its parameter layout and raises."""
+    """Reference: probes.py:309-399.  Transformer variant (4 equal-resolution taps): mvp/dpt.py; ResNet-pyramid variant
+    (4 maps at 8x/4x/2x/1x resolution, bias-free 3x3 input convs, pre-activation fusion units): mvp/dpt_res.py."""
 
     def __init__(self, input_dims, output_dim, hidden_dim=512, kernel_size=3, precision=None):
         super().__init__()

@@ -20,7 +20,8 @@ class DepthLoss(nn.Module):
 
 
 def sig_loss(depth_pr, depth_gt, sigma=0.85, eps=0.001, only_mean=False):
-    """Reference: losses.py:54-74 (as DepthLoss with the gradient term weighted 0)."""
+    """Reference: losses.py:54-74 (as DepthLoss with the gradient term weighted 0).  ``only_mean`` is accepted and unused,
+    exactly as in the reference (losses.py:54: the flag never reaches the arithmetic)."""
     if sigma != 0.85 or eps != 0.001:
         raise NotImplementedError("sig_loss: only the reference defaults are compiled in")
     return MF.depth_loss(depth_pr, depth_gt, 1.0, 0.0, float("inf"))

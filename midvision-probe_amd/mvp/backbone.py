@@ -204,14 +204,14 @@ class ViTBackbone(nn.Module):
         bns = [dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var) for bn in self.batchnorms]
         return bns, (0 if self.training else 1)
 
-    def _extract(self, images: torch.Tensor, n_spatial_from_grid: bool = True):
+    def _extract(self, images: torch.Tensor, n_spatial_from_grid: bool = True, want_cls: bool = False):
         if not images.is_cuda:
             raise lib.MvpError("images must be on the HIP device (no CPU fallback)")
         eng = self.engine()
         bns, mode = self._tap_bn()
         with torch.no_grad():
             taps = eng.forward_taps(images, self.multilayers, bn=bns, bn_mode=mode, tap_input_of_block=self.tap_input_of_block,
-                                    want_cls=self.output in ("cls", "dense-cls"))
+                                    want_cls=want_cls or self.output in ("cls", "dense-cls"))
             if self.add_norm and self.training:
                 torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms], 1)  # one launch for all taps
         return taps

@@ -20,10 +20,21 @@ def remove_module_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch
     return {key.replace("module.", ""): val for key, val in state_dict.items()}
 
 
+def _plain(obj):
+    """cfg as plain containers (what the weights_only loader accepts)."""
+    if isinstance(obj, dict):
+        return {str(k): _plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_plain(v) for v in obj]
+    if isinstance(obj, (str, int, float, bool)) or obj is None:
+        return obj
+    return str(obj)
+
+
 def save_checkpoint(path: str, cfg: Any, model: torch.nn.Module, probe: torch.nn.Module) -> str:
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     # clone to contiguous CPU tensors: probe parameters are views into FlatAdamW's flat buffer
-    ckpt = {"cfg": cfg,
+    ckpt = {"cfg": _plain(cfg),
             "model": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
             "probe": {k: v.detach().cpu().clone() for k, v in probe.state_dict().items()}}
     torch.save(ckpt, path)
@@ -32,7 +43,14 @@ def save_checkpoint(path: str, cfg: Any, model: torch.nn.Module, probe: torch.nn
 
 def load_checkpoint(path: str, model: torch.nn.Module, probe: torch.nn.Module, load_model: bool = False) -> dict:
     """Depth eval loads the probe only (train_depth.py:533-535); snorm eval loads both (train_snorm.py:541-542)."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)  # our own file (cfg may be a plain dict)
+    # weights_only=True: nothing from the file is executed.  save_checkpoint writes plain dicts + tensors, which this accepts.
+    # A reference-written ckpt.pth pickles cfg as an omegaconf DictConfig (train_depth.py:832-844): the safe loader refuses
+    # that object — convert such a file once where omegaconf is installed (torch.save({"probe": ckpt["probe"], "model": ...})).
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:  # pickle.UnpicklingError and friends
+        raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {str(e)[:200]}). Reference checkpoints carry "
+                           "an omegaconf cfg object; re-save their 'probe' / 'model' state dicts as plain tensors first.") from e
     probe_sd = remove_module_prefix(ckpt["probe"])
     with torch.no_grad():  # copy in place: parameters may be views of the optimiser's flat buffer
         own = probe.state_dict()

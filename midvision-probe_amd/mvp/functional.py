@@ -61,6 +61,21 @@ def interpolate(x: torch.Tensor, size=None, scale_factor=None, mode: str = "near
     return _Interpolate.apply(x, Ho, Wo, _MODES[mode], bool(align_corners), sh, sw)
 
 
+def resize_antialias(x: torch.Tensor, size) -> torch.Tensor:
+    """torchvision ``transforms.Resize(size)`` on a float tensor = ``F.interpolate(x, size, mode="bilinear",
+    align_corners=False, antialias=True)`` (dino_res50.py:80,85).  Forward only (frozen-backbone input side)."""
+    _need_cuda(x, "resize_antialias")
+    if x.requires_grad:
+        raise lib.MvpError("resize_antialias is forward-only (input side of the frozen backbone)")
+    x = x.contiguous().float()
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = (size, size) if isinstance(size, int) else tuple(int(v) for v in size)
+    y = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=x.device)
+    a = lib.ResizeArgs(lib.ptr(x), lib.ptr(y), B * C, Hi, Wi, Ho, Wo, lib.RESIZE_BILINEAR, 0, 0, 0, 0.0, 0.0)
+    lib.call("mvp_resize_aa_fwd", a)
+    return y
+
+
 # --------------------------------------------------------------------------- linear head (k = 1)
 def pack_features(feats: Sequence[torch.Tensor], precision: int) -> PackedFeatures:
     """Token-major bf16 operands for the head GEMMs: reuse the packing the backbone wrote next

@@ -114,7 +114,22 @@ class AdamWArgs(C.Structure):
 
 class CorrArgmaxArgs(C.Structure):
     _fields_ = [("src_feat", _vp), ("tgt_feat", _vp), ("kp_xy", _vp), ("out_xy", _vp), ("out_val", _vp),
-                ("workspace", _vp), ("workspace_bytes", _i64), ("C", _i), ("h", _i), ("w", _i), ("K", _i)]
+                ("workspace", _vp), ("workspace_bytes", _i64), ("C", _i), ("h", _i), ("w", _i), ("K", _i), ("heat_out", _vp)]
+
+
+class Argmax2dArgs(C.Structure):
+    _fields_ = [("x", _vp), ("out_xy", _vp), ("K", _i), ("h", _i), ("w", _i), ("max_value", _i)]
+
+
+class ScaleShiftArgs(C.Structure):
+    _fields_ = [("x", _vp), ("scale_shift", _vp), ("grad_out", _vp), ("out", _vp), ("B", _i), ("HW", _i64), ("lo", _f), ("hi", _f),
+                ("clamp", _i), ("backward", _i)]
+
+
+class MetricsBreakdownArgs(C.Structure):
+    _fields_ = [("pred", _vp), ("gt", _vp), ("seg", _vp), ("scale_shift", _vp), ("level_sums", _vp), ("seg_sums", _vp),
+                ("workspace", _vp), ("workspace_bytes", _i64), ("B", _i), ("H", _i), ("W", _i), ("Cp", _i), ("num_levels", _i), ("num_ids", _i),
+                ("t1", _f), ("t2", _f), ("t3", _f)]
 
 
 class ConvWeightPackArgs(C.Structure):
@@ -153,7 +168,7 @@ class MaxpoolClArgs(C.Structure):
 
 class MaskSplitArgs(C.Structure):
     _fields_ = [("src", _vp), ("mask", _vp), ("dst_f32", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("M", _i64), ("N", _i),
-                ("lds", _i), ("ldm", _i), ("ldo", _i)]
+                ("lds", _i), ("ldm", _i), ("ldo", _i), ("relu_mask_out", _vp)]
 
 
 class GemmTnArgs(C.Structure):
@@ -179,6 +194,7 @@ SYMBOLS = {
     "mvp_pack_nchw_tokens": PackNchwArgs,
     "mvp_resize_fwd": ResizeArgs,
     "mvp_resize_bwd": ResizeArgs,
+    "mvp_resize_aa_fwd": ResizeArgs,
     "mvp_depth_predict_fwd": DepthPredictArgs,
     "mvp_depth_predict_bwd": DepthPredictArgs,
     "mvp_depth_loss_workspace_bytes": None,
@@ -189,6 +205,10 @@ SYMBOLS = {
     "mvp_adamw_step": AdamWArgs,
     "mvp_corr_argmax": CorrArgmaxArgs,
     "mvp_corr_workspace_bytes": None,
+    "mvp_argmax_2d": Argmax2dArgs,
+    "mvp_scale_shift": ScaleShiftArgs,
+    "mvp_metrics_breakdown_workspace_bytes": None,
+    "mvp_metrics_breakdown": MetricsBreakdownArgs,
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
     "mvp_mask_split": MaskSplitArgs,
@@ -234,6 +254,8 @@ def load() -> C.CDLL:
     lib.mvp_bn_tokens_workspace_bytes.restype = _i64
     lib.mvp_colsum_workspace_bytes.argtypes = [_i, _i]
     lib.mvp_colsum_workspace_bytes.restype = _i64
+    lib.mvp_metrics_breakdown_workspace_bytes.argtypes = [_i, _i, _i]
+    lib.mvp_metrics_breakdown_workspace_bytes.restype = _i64
     lib.mvp_metrics_workspace_bytes.argtypes = [_i]
     lib.mvp_metrics_workspace_bytes.restype = _i64
     lib.mvp_gemm_splitk_workspace_bytes.argtypes = [_i, _i, _i]

@@ -224,7 +224,7 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, hyper, n, beta1=0.9, beta2=0.99
     lib.call("mvp_adamw_step", a)
 
 
-def corr_argmax(src_feat, tgt_feat, kp_xy, out_xy, out_val, workspace, Cdim, h, w, K) -> None:
+def corr_argmax(src_feat, tgt_feat, kp_xy, out_xy, out_val, workspace, Cdim, h, w, K, heat_out=None) -> None:
     a = lib.CorrArgmaxArgs(lib.ptr(src_feat), lib.ptr(tgt_feat), lib.ptr(kp_xy), lib.ptr(out_xy), lib.ptr(out_val), lib.ptr(workspace),
-                           workspace.numel() * workspace.element_size(), Cdim, h, w, K)
+                           workspace.numel() * workspace.element_size(), Cdim, h, w, K, lib.ptr(heat_out))
     lib.call("mvp_corr_argmax", a)

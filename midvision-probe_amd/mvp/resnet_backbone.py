@@ -101,14 +101,15 @@ class ResNetBackbone(nn.Module):
         return self._engine_obj
 
     def _resize(self, x):
-        """Resize((fixed_size, fixed_size)), dino_res50.py:80,85.  Identity or upsampling is plain bilinear
-        (antialias has no effect); antialiased DOWN-sampling is not on the HIP path."""
+        """Resize((fixed_size, fixed_size)), dino_res50.py:80,85 (torchvision resizes tensors with antialias=True).  Identity or
+        up-sampling on both axes is plain bilinear (the antialias filter degenerates to it); if an axis down-samples (NYU
+        480x640 with center_crop False -> 480x480) the stretched triangle filter of ATen's _upsample_bilinear2d_aa runs."""
         S = self.fixed_size
         H, W = x.shape[-2:]
         if (H, W) == (S, S):
             return x
         if H > S or W > S:
-            raise NotImplementedError("antialiased down-sampling Resize is not on the HIP path (feed fixed_size x fixed_size or smaller images)")
+            return MF.resize_antialias(x, (S, S))
         return MF.interpolate(x, size=(S, S), mode="bilinear", align_corners=False)
 
     def forward(self, x):

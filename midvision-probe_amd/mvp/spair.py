@@ -11,9 +11,21 @@ import torch
 from . import lib, ops
 
 
-def correspondence(feats_i: torch.Tensor, feats_j: torch.Tensor, kps_i_xy01: torch.Tensor):
+def argmax_2d(x: torch.Tensor, max_value: bool = True) -> torch.Tensor:
+    """Reference: evals/utils/correspondence.py:179-190 — x [..., h, w] -> [..., 2] int64 (col, row) of the flat argmax
+    (argmin when max_value=False); ties resolve to the lowest flat index, as torch."""
+    if not x.is_cuda:
+        raise lib.MvpError("argmax_2d needs a device tensor (no CPU fallback)")
+    h, w = x.shape[-2:]
+    xs = x.detach().reshape(-1, h, w).contiguous().float()
+    out = torch.empty(xs.shape[0], 2, dtype=torch.int64, device=x.device)
+    lib.call("mvp_argmax_2d", lib.Argmax2dArgs(lib.ptr(xs), lib.ptr(out), xs.shape[0], h, w, int(bool(max_value))))
+    return out.view(*x.shape[:-2], 2)
+
+
+def correspondence(feats_i: torch.Tensor, feats_j: torch.Tensor, kps_i_xy01: torch.Tensor, return_heatmaps: bool = False):
     """feats_* [C,h,w] fp32 device maps (un-normalised), kps_i_xy01 [K,2] in [0,1] (x,y).
-    Returns (pred_xy [K,2] int64 (col,row), max_val [K]) on the device."""
+    Returns (pred_xy [K,2] int64 (col,row), max_val [K]) on the device (+ heat-maps [K,h,w] when asked)."""
     if not feats_i.is_cuda:
         raise lib.MvpError("spair.correspondence needs device tensors (no CPU fallback)")
     C, h, w = feats_i.shape
@@ -23,15 +35,18 @@ def correspondence(feats_i: torch.Tensor, feats_j: torch.Tensor, kps_i_xy01: tor
     out_xy = torch.empty(K, 2, dtype=torch.int64, device=dev)
     out_val = torch.empty(K, dtype=torch.float32, device=dev)
     ws = torch.empty((int(lib.load().mvp_corr_workspace_bytes(C, h, w, K)) + 3) // 4, dtype=torch.float32, device=dev)
-    ops.corr_argmax(feats_i.contiguous().float(), feats_j.contiguous().float(), ndc, out_xy, out_val, ws, C, h, w, K)
-    return out_xy, out_val
+    heat = torch.empty(K, h, w, dtype=torch.float32, device=dev) if return_heatmaps else None
+    ops.corr_argmax(feats_i.contiguous().float(), feats_j.contiguous().float(), ndc, out_xy, out_val, ws, C, h, w, K, heat_out=heat)
+    return (out_xy, out_val, heat) if return_heatmaps else (out_xy, out_val)
 
 
 def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
     """Reference: evaluate_spair_correspondence.py:45-103.  ``instance`` =
     (img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _)."""
-    if mask_feats or return_heatmaps:
-        raise NotImplementedError("mask_feats / return_heatmaps are outside the hot path (heat-maps are never materialised)")
+    if mask_feats:
+        # the reference multiplies feats [2,C,h,w] by masks [2,h,w] (evaluate_spair_correspondence.py:61-62): that broadcast only
+        # type-checks for C == 2, i.e. it raises for every real backbone; no caller in the reference passes mask_feats=True
+        raise NotImplementedError("mask_feats=True does not broadcast in the reference either (feats [2,C,h,w] * masks [2,h,w])")
     img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _ = instance
     dev = torch.device("cuda", torch.cuda.current_device())
     images = torch.stack((img_i, img_j)).to(dev)
@@ -43,7 +58,8 @@ def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
     kps_j = kps_j.float().clone()
     kps_i[:, :2] = kps_i[:, :2] / images.shape[-1]
     kps_j[:, :2] = kps_j[:, :2] / images.shape[-1]
-    pred_xy, _ = correspondence(feats[0], feats[1], kps_i[:, :2])
+    res = correspondence(feats[0], feats[1], kps_i[:, :2], return_heatmaps=return_heatmaps)
+    pred_xy = res[0]
     pred_kp = pred_xy.float().cpu() / feats.shape[-1]
     errors = (pred_kp[:, None, :] - kps_j[None, :, :2]).norm(p=2, dim=-1)
     errors = errors / thresh_scale
@@ -53,6 +69,8 @@ def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
     error_same = errors.diagonal()[in_both]
     error_nn, index_nn = errors[in_both].min(dim=1)
     index_same = in_both.nonzero().squeeze(1)
+    if return_heatmaps:
+        return error_same, error_nn, index_same, index_nn, res[2]
     return error_same, error_nn, index_same, index_nn
 
 

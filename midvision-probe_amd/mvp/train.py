@@ -34,7 +34,7 @@ def _finish_pending(optimizer):
         fin()
 
 
-def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model=True):
+def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model=True, scale_invariant=False):
     """One iteration of train_depth.py:99-143; returns the loss as a DEVICE scalar (the
     reference's per-step ``loss.item()`` host sync is left to the caller)."""
     optimizer.zero_grad()
@@ -42,6 +42,10 @@ def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target
     _finish_pending(optimizer)
     pred = probe(feats)
     pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
+    if scale_invariant:  # train_depth.py:116-118: per-image scale/shift fit (detached) + clamp, one fused kernel each way
+        from evals.utils.metrics import match_scale_and_shift
+
+        pred = match_scale_and_shift(pred, target, clamp=(0.001, 1.0))
     loss = loss_fn(pred, target)
     loss.backward()
     optimizer.step()
@@ -83,8 +87,6 @@ def _device_batches(loader, dev, keys=("image", "depth", "snorm")):
 def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_model, loss_fn, rank=0, world_size=1,
           valid_loader=None, scale_invariant=False, wandb_use=False, is_final=False, is_navi=False, log_every=0):
     """Reference signature: train_depth.py:76-92.  Batches are dicts {"image", "depth"} (nyu.py:245-251)."""
-    if scale_invariant:
-        raise NotImplementedError("scale_invariant training (match_scale_and_shift) is outside the hot path")
     dev = torch.device("cuda", torch.cuda.current_device())
     history = []
     for ep in range(n_epochs):
@@ -94,31 +96,48 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
         for i, batch in enumerate(_device_batches(train_loader, dev)):
             images = batch["image"].to(dev, non_blocking=True)
             target = batch["depth"].to(dev, non_blocking=True).contiguous()
-            loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model)
+            loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model, scale_invariant)
             train_loss += loss.item()  # the reference syncs every step too (train_depth.py:143)
         history.append(train_loss / max(len(train_loader), 1))
     return history
 
 
-def validate(model, probe, loader, loss_fn, verbose=True, scale_invariant=False, aggregate=True):
-    """Reference: validate(), train_depth.py:357-483 (global metrics; W&B / per-image dumps /
-    segment breakdowns are outside the hot path).  Returns (mean loss, {metric: mean})."""
-    from evals.utils.metrics import evaluate_depth, match_scale_and_shift
+def validate(model, probe, loader, loss_fn, verbose=True, scale_invariant=False, aggregate=True, render_images=False, wandb_use=False,
+             is_navi=False, output_dir="result"):
+    """Reference: validate(), train_depth.py:357-483 -> (mean loss, global_metrics, level_metrics).  Global metrics include the
+    stuff/things groups when ``is_navi`` is False (batches then carry "segmentation", nyu.py:245-251); per-segment rows are
+    collected in ``validate.last_segment_metrics`` (the reference only plots them).  PNG dumps / W&B are out of scope."""
+    from evals.utils.metrics import evaluate_depth
 
     dev = torch.device("cuda", torch.cuda.current_device())
-    total_loss, sums, count = 0.0, {}, 0
+    total_loss, count = 0.0, 0
+    global_metrics, level_metrics, segments = None, None, []
     with torch.no_grad():
-        for batch in _device_batches(loader, dev):
+        for batch in _device_batches(loader, dev, keys=("image", "depth", "snorm", "segmentation")):
             images = batch["image"].to(dev)
             target = batch["depth"].to(dev).contiguous()
+            seg = None if is_navi else batch["segmentation"].to(dev)
             feats = model(images)
             pred = probe(feats)
             pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
             loss = loss_fn(pred, target)
             total_loss += loss.item()
-            gm, _, _ = evaluate_depth(pred, target, None, scale_invariant=scale_invariant, is_navi=True)
-            for k, v in gm.items():
-                sums.setdefault(k, []).append(v.reshape(-1))
+            gm, lm, sm = evaluate_depth(pred, target, seg, scale_invariant=scale_invariant, nyu_crop=not is_navi, is_navi=is_navi)
+            segments.extend(sm)
+            if global_metrics is None:
+                global_metrics = {k: [v.reshape(-1)] for k, v in gm.items()}
+                level_metrics = {L: {k: [v] for k, v in d.items()} for L, d in lm.items()}
+            else:
+                for k, v in gm.items():
+                    global_metrics[k].append(v.reshape(-1))
+                for L, d in lm.items():
+                    for k, v in d.items():
+                        level_metrics[L][k].append(v)
             count += 1
-    metrics = {k: (torch.cat(v).mean().item() if aggregate else torch.cat(v)) for k, v in sums.items()}
-    return total_loss / max(count, 1), metrics
+    if global_metrics is None:
+        raise ValueError("validate(): empty loader")
+    if aggregate:
+        global_metrics = {k: torch.cat(v, dim=0).mean() for k, v in global_metrics.items()}
+        level_metrics = {L: {k: torch.cat(v, dim=0).mean() for k, v in d.items()} for L, d in level_metrics.items()}
+    validate.last_segment_metrics = segments
+    return total_loss / max(count, 1), global_metrics, level_metrics

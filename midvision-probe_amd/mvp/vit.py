@@ -52,6 +52,7 @@ class PackedFeatures:
         self.Cpad = (Ctot + 127) // 128 * 128  # NT GEMM K % 64, TN kernel Cin % 128; pad columns stay zero
         self.tok = ops.zeros_pair((self.Mpad, self.Cpad), precision, device)
         self.sources: List[Tuple[int, int]] = []  # (data_ptr, _version) of the NCHW maps packed here
+        self.source_refs: List[torch.Tensor] = []  # the maps themselves: while they live, their addresses cannot be recycled
         self.generation = 0  # bumped every time the buffers are rewritten (they are reused across steps)
         self.scratch: Dict[str, object] = {}  # per-shape scratch of the head backward (zero-padded once)
 
@@ -67,7 +68,11 @@ def _ver(t: torch.Tensor) -> int:
 
 
 def register_pack(maps: Sequence[torch.Tensor], pack: PackedFeatures) -> None:
+    """The cache key is (data_ptr, _version) of each map.  The registry also KEEPS the maps (strong references, dropped at the next
+    backbone forward): were they freed, the caching allocator could hand the same addresses to unrelated same-shape tensors with
+    version 0 (re-uploaded cached features, clones), which would then silently alias this packing."""
     pack.sources = [(m.data_ptr(), _ver(m)) for m in maps]
+    pack.source_refs = list(maps)
     _PACK_REGISTRY.clear()  # single most-recent entry: the probe consumes features right after the backbone
     _PACK_REGISTRY[maps[0].data_ptr()] = pack
 
@@ -80,8 +85,8 @@ def lookup_pack(maps: Sequence[torch.Tensor]) -> Optional[PackedFeatures]:
     pack = _PACK_REGISTRY.get(maps[0].data_ptr())
     if pack is None or len(pack.sources) != len(maps):
         return None
-    for m, (p, v) in zip(maps, pack.sources):
-        if m.data_ptr() != p or _ver(m) != v:
+    for m, (p, v), src in zip(maps, pack.sources, pack.source_refs):
+        if m.data_ptr() != p or _ver(m) != v or m.shape != src.shape or m.dtype != src.dtype or m.stride() != src.stride():
             return None
     return pack
 

@@ -23,7 +23,10 @@ def main(argv):
     from mvp import functional as MF
 
     cfg = config.compose("snorm_training", argv)
+    if float(cfg["optimizer"].get("model_lr", 0.0)) != 0.0:
+        raise NotImplementedError("optimizer.model_lr != 0 (backbone fine-tuning) is outside the frozen-backbone hot path")
     rank, local, world = mdist.env_setup("nccl")
+    torch.manual_seed(int(cfg["system"]["random_seed"]))
     dev = torch.device("cuda", torch.cuda.current_device())
     ds = cfg["dataset"]
     from evals.datasets import build_loader
@@ -34,7 +37,7 @@ def main(argv):
     nb = len(loader)
     model = config.instantiate(cfg["backbone"]).to(dev)
     probe = config.instantiate(cfg["probe"], feat_dim=model.feat_dim).to(dev)
-    opt = FlatAdamW([{"params": probe.parameters(), "lr": cfg["optimizer"]["probe_lr"]}])
+    opt = FlatAdamW([{"params": probe.parameters(), "lr": cfg["optimizer"]["probe_lr"]}], overlap_comm=world > 1)
     n_ep = cfg["optimizer"]["n_epochs"]
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, n_ep * nb, cfg["optimizer"]["warmup_epochs"] * nb))
     for ep in range(n_ep):
@@ -47,6 +50,7 @@ def main(argv):
             tot += train_snorm_step(model, probe, opt, sched, images, target, mask).item()
         if rank == 0:
             print(f"epoch {ep} train loss {tot / nb:.4f}")
+    opt.finish_pending()
     if rank == 0:
         model.eval(); probe.eval()
         b = next(iter(build_loader(dict(ds, num_batches=1, batch_size=B), "valid", B)))

@@ -24,7 +24,7 @@ def match_scale_and_shift(prediction, target):
     scale, shift = torch.ones_like(b0), torch.zeros_like(b1)
     scale[ok] = (a11[ok] * b0[ok] - a01[ok] * b1[ok]) / det[ok]
     shift[ok] = (-a01[ok] * b0[ok] + a00[ok] * b1[ok]) / det[ok]
-    out = prediction * scale.view(-1, 1, 1) + shift.view(-1, 1, 1)
+    out = prediction * scale.view(-1, 1, 1).detach() + shift.view(-1, 1, 1).detach()  # metrics.py:775-776: no gradient through the fit
     return out[:, None] if four else out
 
 

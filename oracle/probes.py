@@ -61,7 +61,39 @@ def make_dpt_weights(input_dims, out_dim: int, hidden: int = 512, k: int = 3, se
     return sd
 
 
+def make_multiscale_weights(input_dims, out_dim: int, hidden: int = 512, k: int = 1, seed: int = 0) -> StateDict:
+    """Key layout of MultiscaleHead (probes.py:435-445): head.convs.i, head.conv_mid.{0,2,4}, head.conv_out.{0,2}."""
+    g = torch.Generator().manual_seed(seed)
+    dims = [d if isinstance(d, int) else d[0] for d in input_dims]
+    sd: StateDict = {}
+
+    def put(name, cout, cin):
+        sd[name + ".weight"], sd[name + ".bias"] = _conv_init(g, cout, cin, k)
+
+    for i, d in enumerate(dims):
+        put(f"head.convs.{i}", hidden, d)
+    put("head.conv_mid.0", hidden, len(dims) * hidden)
+    put("head.conv_mid.2", hidden, hidden)
+    put("head.conv_mid.4", hidden, hidden)
+    put("head.conv_out.0", hidden, hidden)
+    put("head.conv_out.2", out_dim, hidden)
+    return sd
+
+
 # --------------------------------------------------------------------------- heads
+def multiscale_head(sd: StateDict, feats: Sequence[torch.Tensor]) -> torch.Tensor:
+    """probes.py:447-458 MultiscaleHead.forward (convs carry no padding, probes.py:400-412)."""
+    c = lambda n, x: F.conv2d(x, sd[f"head.{n}.weight"], sd[f"head.{n}.bias"])  # noqa: E731
+    fs = [c(f"convs.{i}", f) for i, f in enumerate(feats)]
+    h, w = fs[-1].shape[-2:]
+    x = torch.cat([F.interpolate(f, (h, w), mode="bilinear") for f in fs], dim=1).relu()
+    x = F.interpolate(x, scale_factor=2, mode="bilinear")
+    x = c("conv_mid.4", c("conv_mid.2", c("conv_mid.0", x).relu()).relu()).relu()
+    x = F.interpolate(x, scale_factor=4, mode="bilinear")
+    return c("conv_out.2", c("conv_out.0", x).relu())
+
+
+
 def linear_head(sd: StateDict, feats, k: int = 1) -> torch.Tensor:
     """probes.py:427-432 — cat maps on C, bilinear x4 (align_corners=False), conv k x k."""
     if isinstance(feats, (list, tuple)):
@@ -136,7 +168,7 @@ def depth_sigmoid_prediction(x: torch.Tensor, min_depth: float = 0.001, max_dept
 
 def depth_head(sd, feats, head_type="linear", k=1, prediction_type="bindepth", min_depth=0.001, max_depth=10):
     """probes.py:153-157 DepthHead.forward."""
-    x = linear_head(sd, feats, k) if head_type == "linear" else dpt_head(sd, list(feats), k)
+    x = linear_head(sd, feats, k) if head_type == "linear" else (multiscale_head(sd, list(feats)) if head_type == "multiscale" else dpt_head(sd, list(feats), k))
     if prediction_type == "bindepth":
         return depth_bin_prediction(x, min_depth, max_depth, 256)
     return depth_sigmoid_prediction(x, min_depth, max_depth)
@@ -144,4 +176,6 @@ def depth_head(sd, feats, head_type="linear", k=1, prediction_type="bindepth", m
 
 def snorm_head(sd, feats, head_type="dpt", k=3):
     """probes.py:115-116 SurfaceNormalHead.forward."""
+    if head_type == "multiscale":
+        return multiscale_head(sd, list(feats))
     return linear_head(sd, feats, k) if head_type == "linear" else dpt_head(sd, list(feats), k)

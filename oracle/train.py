@@ -21,7 +21,7 @@ class DepthProbeTrainer:
 
     def __init__(self, vit_sd, probe_sd, layers=(2, 5, 8, 11), heads=12, patch=16, head_type="linear", k=1,
                  prediction_type="bindepth", min_depth=0.001, max_depth=10, lr=5e-4, max_step=1000, warmup_step=150,
-                 add_norm=True):
+                 add_norm=True, scale_invariant=False):
         self.vit_sd = vit_sd
         self.probe_sd = {n: t.clone().requires_grad_(True) for n, t in probe_sd.items()}
         self.names = list(self.probe_sd)
@@ -32,6 +32,7 @@ class DepthProbeTrainer:
         self.min_depth, self.max_depth = min_depth, max_depth
         self.base_lr, self.max_step, self.warmup_step = lr, max_step, warmup_step
         self.add_norm = add_norm
+        self.scale_invariant = scale_invariant
         self.t = 0
         C = vit_sd["cls_token"].shape[-1]
         self.bn_running = [(torch.zeros(C), torch.ones(C)) for _ in layers]
@@ -49,6 +50,10 @@ class DepthProbeTrainer:
         pred = probes.depth_head(self.probe_sd, feats, self.head_type, self.k, self.prediction_type,
                                  self.min_depth, self.max_depth)
         pred = F.interpolate(pred, size=target.shape[-2:], mode="bilinear")
+        if self.scale_invariant:  # train_depth.py:116-118
+            from . import metrics
+
+            pred = metrics.match_scale_and_shift(pred, target).clamp(min=0.001, max=1.0)
         return losses.depth_loss(pred, target), pred
 
     def step(self, images: torch.Tensor, target: torch.Tensor, grad_hook=None) -> float:

@@ -190,6 +190,36 @@ def golden_probes(pr):
     np.savez_compressed(os.path.join(OUT, "probes.npz"), **out)
 
 
+def golden_probes_multiscale(pr):
+    """G3b: MultiscaleHead (probes.py:435-458; DepthHead's default head_type) on tiny dims, ViT-style equal-resolution taps and a
+    ResNet-style pyramid (maps resampled to the last one's size): outputs + parameter gradients of the reference module."""
+    out = {}
+    g = torch.Generator().manual_seed(33)
+    B, C, h, w = 2, 24, 5, 7
+    vit_feats = [torch.randn(B, C, h, w, generator=g) for _ in range(4)]
+    rdims = [(8, 0), (12, 0), (16, 0), (20, 0)]
+    res_feats = [torch.randn(B, rdims[i][0], 3 * 2 ** (3 - i), 4 * 2 ** (3 - i), generator=g) for i in range(4)]
+    out["vit_feats"] = np.stack([_np(f) for f in vit_feats])
+    for i, f in enumerate(res_feats):
+        out[f"res_feat{i}"] = _np(f)
+    for name, kind, kw, src in (("depth_ms_bindepth", "depth", dict(prediction_type="bindepth"), "vit"),
+                                ("depth_ms_sigdepth_res", "depth", dict(prediction_type="sigdepth"), "res"),
+                                ("snorm_ms_ua", "snorm", dict(uncertainty_aware=True), "vit")):
+        feat_dim = [C] * 4 if src == "vit" else [d[0] for d in rdims]  # (the reference's MultiscaleHead takes plain ints only)
+        feats = vit_feats if src == "vit" else res_feats
+        probe = (pr.DepthHead if kind == "depth" else pr.SurfaceNormalHead)(feat_dim=feat_dim, head_type="multiscale", hidden_dim=16, kernel_size=1, **kw)
+        odim = probe.head.conv_out[2].out_channels
+        probe.load_state_dict(oprobes.make_multiscale_weights(feat_dim, odim, hidden=16, k=1, seed=19), strict=True)
+        y = probe([f.clone() for f in feats])
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(29))
+        (y * gy).sum().backward()
+        out[f"{name}__out"], out[f"{name}__gy"], out[f"{name}__name"] = _np(y), _np(gy), np.array(probe.name)
+        for n, gr in _grads(probe).items():
+            out[f"{name}__grad__{n}"] = gr
+        print("probe", name, tuple(y.shape), probe.name)
+    np.savez_compressed(os.path.join(OUT, "probes_multiscale.npz"), **out)
+
+
 def golden_losses(ls):
     """G4: DepthLoss (B in {1,2,3,5,8,16} pins quirk Q1), sig_loss, gradient_loss,
     angular_loss (UA on/off): values + input grads."""
@@ -412,6 +442,26 @@ def golden_metrics_breakdown():
     print("metrics_seg", len(out), "arrays;", {k: v.shape for k, v in out.items() if k.startswith("a_sa_level_1")})
 
 
+def golden_si_train(ls):
+    """The scale_invariant branch of the train loop (train_depth.py:114-118): pred -> match_scale_and_shift (scale / shift
+    DETACHED, metrics.py:775-776) -> clamp(0.001, 1.0) -> DepthLoss; loss and d loss / d pred from the reference's own functions."""
+    _stub_loguru()
+    mt = importlib.import_module("evals.utils.metrics")
+    out = {}
+    g = torch.Generator().manual_seed(600)
+    B, H, W = 3, 24, 32
+    tgt = torch.rand(B, 1, H, W, generator=g) * 0.9 + 0.05           # relative depth in (0, 1] as navi_reldepth
+    tgt[torch.rand(tgt.shape, generator=g) < 0.15] = 0
+    pred = (tgt * 1.7 + 0.2 + 0.25 * torch.randn(B, 1, H, W, generator=g)).requires_grad_(True)  # some values leave [0.001, 1] after the fit
+    p2 = mt.match_scale_and_shift(pred, tgt)
+    p3 = p2.clamp(min=0.001, max=1.0)
+    loss = ls.DepthLoss()(p3, tgt.clone())
+    loss.backward()
+    out.update(pred=_np(pred), target=_np(tgt), matched=_np(p2), clamped=_np(p3), loss=np.array(loss.item()), grad=_np(pred.grad))
+    np.savez_compressed(os.path.join(OUT, "si_train.npz"), **out)
+    print("si_train loss", loss.item(), "clamped fraction", float(((p2 < 0.001) | (p2 > 1.0)).float().mean()))
+
+
 def golden_spair():
     """G8: argmax_2d (evals/utils/correspondence.py:179-190) from the reference module itself.  Its top-level
     ``import faiss`` / ``faiss.contrib.torch_utils`` / ``faiss.StandardGpuResources()`` (correspondence.py:4-5,11) are
@@ -463,13 +513,15 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     vt, pr, ls, op = _load_reference()
-    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics", "metrics_seg", "spair"]
+    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics", "metrics_seg", "spair", "probes_multiscale", "si_train"]
     if "vit_tiny" in which:
         golden_vit_tiny(vt)
     if "vit_tiny128" in which:
         golden_vit_tiny(vt, embed_dim=128, heads=2, fname="vit_tiny128.npz")
     if "probes" in which:
         golden_probes(pr)
+    if "probes_multiscale" in which:
+        golden_probes_multiscale(pr)
     if "losses" in which:
         golden_losses(ls)
     if "optim" in which:
@@ -482,6 +534,8 @@ def main():
         golden_metrics()
     if "metrics_seg" in which:
         golden_metrics_breakdown()
+    if "si_train" in which:
+        golden_si_train(ls)
     if "spair" in which:
         golden_spair()
 

@@ -5,6 +5,18 @@ import torch
 from oracle import probes as oprobes
 
 
+def _boom():
+    FakeDictConfig.executed = True
+    return FakeDictConfig()
+
+
+class FakeDictConfig:  # stands in for omegaconf.DictConfig (not installed): unpickling it would run _boom()
+    executed = False
+
+    def __reduce__(self):
+        return (_boom, ())
+
+
 def test_probe_checkpoint_roundtrip(tmp_path):
     from evals.models.probes import DepthHead
     from mvp import checkpoint as ck
@@ -14,7 +26,7 @@ def test_probe_checkpoint_roundtrip(tmp_path):
     probe.load_state_dict(sd, strict=True)
     model = torch.nn.Linear(2, 2)
     path = ck.save_checkpoint(str(tmp_path / "exp" / "ckpt.pth"), {"note": "x"}, model, probe)
-    blob = torch.load(path, weights_only=False)
+    blob = torch.load(path, weights_only=True)  # plain dicts + tensors only: nothing in the file needs executing
     assert set(blob) == {"cfg", "model", "probe"} and set(blob["probe"]) == set(sd)
     # reference checkpoints written from DDP-wrapped modules carry "module." prefixes
     blob["probe"] = {"module." + k: v for k, v in blob["probe"].items()}
@@ -24,6 +36,27 @@ def test_probe_checkpoint_roundtrip(tmp_path):
     for k, v in probe2.state_dict().items():
         assert torch.equal(v, sd[k]), k
     assert probe2.name == "bindepth_dpt_k3"
+
+
+def test_checkpoint_with_object_cfg_is_refused_not_unpickled(tmp_path):
+    """A reference ckpt.pth pickles cfg as an omegaconf DictConfig (train_depth.py:832-844).  load_checkpoint uses the
+    weights_only loader: an arbitrary pickled object must be refused with a clear error, never executed; and a non-plain cfg
+    handed to save_checkpoint is flattened so that our own files always load."""
+    import pytest
+
+    from evals.models.probes import DepthHead
+    from mvp import checkpoint as ck
+
+    probe = DepthHead(feat_dim=[32] * 4, head_type="linear", prediction_type="sigdepth", kernel_size=1)
+    model = torch.nn.Linear(2, 2)
+    bad = str(tmp_path / "ref_style.pth")
+    torch.save({"cfg": FakeDictConfig(), "model": model.state_dict(), "probe": probe.state_dict()}, bad)
+    with pytest.raises(RuntimeError, match="weights_only"):
+        ck.load_checkpoint(bad, model, probe)
+    assert FakeDictConfig.executed is False
+    good = ck.save_checkpoint(str(tmp_path / "own.pth"), {"obj": FakeDictConfig(), "n": 3, "l": (1, 2)}, model, probe)
+    out = ck.load_checkpoint(good, model, probe)
+    assert out["cfg"]["n"] == 3 and out["cfg"]["l"] == [1, 2] and isinstance(out["cfg"]["obj"], str)
 
 
 def test_ssl_resnet50_wrapper_surface():

@@ -9,7 +9,9 @@ def test_sample_contract_and_determinism():
     ds = SyntheticNYU("train", num_samples=6, image_size=(32, 48), max_depth=10.0)
     s0, s0b = ds[0], ds[0]
     assert s0["image"].shape == (3, 32, 48) and s0["depth"].shape == (1, 32, 48) and s0["snorm"].shape == (3, 32, 48)
-    assert all(v.dtype == torch.float32 for v in s0.values())
+    assert all(v.dtype == torch.float32 for k, v in s0.items() if k != "segmentation")
+    seg = s0["segmentation"]  # nyu.py:245-251 carries the OneFormer panoptic map the per-segment metrics read
+    assert seg.dtype == torch.int64 and seg.shape == (32, 48) and 0 <= int(seg.min()) and int(seg.max()) < 150
     assert all(torch.equal(s0[k], s0b[k]) for k in s0)  # pure function of the index
     assert not torch.equal(ds[1]["image"], s0["image"])
     assert not torch.equal(SyntheticNYU("valid", 6, (32, 48))[0]["image"], s0["image"])
@@ -26,7 +28,7 @@ def test_build_loader_single_process():
     sizes = [b["image"].shape[0] for b in va]
     assert sizes == [4, 4, 2]  # drop_last=False
     b = next(iter(va))
-    assert set(b) == {"image", "depth", "snorm"} and b["depth"].shape == (4, 1, 16, 16)
+    assert set(b) == {"image", "depth", "snorm", "segmentation"} and b["depth"].shape == (4, 1, 16, 16)
 
 
 def test_build_loader_distributed_sampler_matches_shard_indices():
@@ -45,4 +47,4 @@ def test_build_loader_distributed_sampler_matches_shard_indices():
 def test_build_loader_from_config_node():
     ld = build_loader({"name": "synthetic", "image_size": [16, 24], "num_batches": 3, "batch_size": 2, "max_depth": 10}, "train", 2, with_snorm=False)
     b = next(iter(ld))
-    assert len(ld) == 3 and set(b) == {"image", "depth"} and b["image"].shape == (2, 3, 16, 24)
+    assert len(ld) == 3 and set(b) == {"image", "depth", "segmentation"} and b["image"].shape == (2, 3, 16, 24)

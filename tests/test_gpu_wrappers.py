@@ -192,6 +192,23 @@ def test_spair_correspondence_vs_oracle(dev):
     assert (xy2.cpu() == 0).all()
 
 
+def test_argmax_2d_and_correspondence_vs_reference_golden(dev, golden):
+    """correspondence.py:179-190 from the reference module itself (tests/golden/spair.npz): integer indices, bit-exact,
+    exact ties (first maximum / first minimum), both through the standalone kernel and through the fused corr_argmax."""
+    from mvp import spair
+
+    g = golden("spair.npz")
+    for key_in, mx, key_out in (("heat", True, "pred_max"), ("heat", False, "pred_min"), ("tie_heat", True, "tie_max"), ("tie_heat", False, "tie_min")):
+        xy = spair.argmax_2d(torch.from_numpy(g[key_in]).to(dev), max_value=mx)
+        np.testing.assert_array_equal(xy.cpu().numpy(), g[key_out])
+    feats = torch.from_numpy(g["feats"]).to(dev)
+    xy, val, heat = spair.correspondence(feats[0], feats[1], torch.from_numpy(g["kps01"]), return_heatmaps=True)
+    np.testing.assert_array_equal(xy.cpu().numpy(), g["pred_max"])          # incl. the planted exact tie of keypoint 2
+    np.testing.assert_allclose(heat.cpu().numpy(), g["heat"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_array_equal(spair.argmax_2d(heat).cpu().numpy(), xy.cpu().numpy())
+    assert rel_l2(val.cpu().numpy(), g["heat"].reshape(g["heat"].shape[0], -1).max(1)) < 1e-5
+
+
 def test_spair_compute_errors_end_to_end(dev):
     """compute_errors (evaluate_spair_correspondence.py:45-103) with the iBOT wrapper on a synthetic pair."""
     from evals.models.ibot import iBOT
@@ -207,7 +224,8 @@ def test_spair_compute_errors_end_to_end(dev):
     kps_j = torch.cat([torch.rand(K, 2, generator=g) * 159, (torch.rand(K, 1, generator=g) > 0.2).float()], 1)
     inst = (img_i, np.ones((160, 160)), kps_i, img_j, np.ones((160, 160)), kps_j, 0.7, None)
     model = iBOT(add_norm=True, weights=sd).to(dev)  # single tap, train-mode BN over the pair (as the reference)
-    e_same, e_nn, i_same, i_nn = spair.compute_errors(model, inst)
+    e_same, e_nn, i_same, i_nn, heat = spair.compute_errors(model, inst, return_heatmaps=True)
+    assert tuple(heat.shape) == (K, 10, 10)
     # oracle
     feats = ovit.vit_dense_features(sd, torch.stack((img_i, img_j)), [DEPTH - 1], heads=HEADS)
     ki, kj = kps_i.clone(), kps_j.clone()

@@ -105,6 +105,21 @@ def test_probe_fwd_bwd(case):
         assert rel_l2(t.grad.numpy(), ref) < 2e-4, n
 
 
+@pytest.mark.parametrize("name,kind,src,odim", [("depth_ms_bindepth", "depth", "vit", 256), ("depth_ms_sigdepth_res", "depth", "res", 1), ("snorm_ms_ua", "snorm", "vit", 4)])
+def test_multiscale_head_fwd_bwd(name, kind, src, odim):
+    """MultiscaleHead (probes.py:435-458) vs outputs + grads of the reference module (golden probes_multiscale.npz)."""
+    g = load_golden("probes_multiscale.npz")
+    feats = [T(g["vit_feats"][i]) for i in range(4)] if src == "vit" else [T(g[f"res_feat{i}"]) for i in range(4)]
+    fdim = [24] * 4 if src == "vit" else [(8, 0), (12, 0), (16, 0), (20, 0)]
+    sd = {n: t.requires_grad_(True) for n, t in oprobes.make_multiscale_weights(fdim, odim, hidden=16, k=1, seed=19).items()}
+    y = oprobes.depth_head(sd, feats, "multiscale", 1, "bindepth" if odim == 256 else "sigdepth") if kind == "depth" else oprobes.snorm_head(sd, feats, "multiscale", 1)
+    assert str(g[f"{name}__name"]) == {"depth_ms_bindepth": "bindepth_multiscale_k1", "depth_ms_sigdepth_res": "sigdepth_multiscale_k1", "snorm_ms_ua": "snorm_multiscale_k1_UA"}[name]
+    assert rel_l2(y.detach().numpy(), g[f"{name}__out"]) < TOL
+    (y * T(g[f"{name}__gy"])).sum().backward()
+    for n, t in sd.items():
+        assert rel_l2(t.grad.numpy(), g[f"{name}__grad__{n}"]) < 2e-4, n
+
+
 # ------------------------------------------------------------------ losses
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 16])
 def test_depth_loss(B):

@@ -72,3 +72,19 @@ def test_argmax_2d_vs_reference_golden(golden):
     pred, heat = osp.correspondence(torch.from_numpy(g["feats"]), torch.from_numpy(g["kps01"]))
     np.testing.assert_array_equal(pred.numpy(), g["pred_max"])
     np.testing.assert_allclose(heat.numpy(), g["heat"], rtol=1e-5, atol=1e-6)
+
+
+def test_scale_invariant_train_branch_vs_reference_golden(golden):
+    """train_depth.py:114-118 (match_scale_and_shift with DETACHED scale/shift -> clamp -> DepthLoss): loss and input gradient."""
+    from oracle import losses as ol
+    from oracle import metrics as om
+
+    g = golden("si_train.npz")
+    pred = torch.from_numpy(g["pred"]).requires_grad_(True)
+    tgt = torch.from_numpy(g["target"])
+    p2 = om.match_scale_and_shift(pred, tgt)
+    np.testing.assert_allclose(p2.detach().numpy(), g["matched"], rtol=2e-5, atol=2e-6)
+    loss = ol.depth_loss(p2.clamp(min=0.001, max=1.0), tgt.clone())
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    np.testing.assert_allclose(pred.grad.numpy(), g["grad"], rtol=1e-4, atol=1e-7)
