@@ -127,14 +127,20 @@ typedef struct {
    * the fp32 partial tiles in a fixed order (bit-reproducible) and runs the fused epilogue.  For GEMMs
    * with too few output tiles to fill 256 CUs (N = 768 projections, the probe head at M ~ 3k rows).
    * splitk_ws: >= mvp_gemm_splitk_workspace_bytes(M, N, splitk) bytes whose leading tile counters are ZERO
-   * at first use (they reset themselves); not shared by GEMMs running concurrently on other streams.   */
+   * at first use (they reset themselves); not shared by GEMMs running concurrently on other streams.
+   * splitk == MVP_GEMM_STREAMK (-1): stream-K scheduling instead (csrc/gemm_sk.hip): one workgroup per CU, every CU gets the
+   * same number of k-iterations of 128x128x64 tiles whatever the tile count; same bit-reproducible fixed-order reduction of
+   * partial tiles; splitk_ws >= mvp_gemm_streamk_workspace_bytes(), 16-byte aligned, counters ZERO at first use.        */
   int splitk; void* splitk_ws; int64_t splitk_ws_bytes;
   /* --- optional residual given as a bf16 pair (row stride ldr, elements), added like `residual`:
    * lets a frozen trunk keep block outputs only as pairs (ResNet identities, dino_res50.py:83-101). */
   const mvp_bf16* residual_hi; const mvp_bf16* residual_lo;
 } mvp_gemm_args;
+#define MVP_GEMM_STREAMK (-1)
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
 int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits);
+int64_t mvp_gemm_streamk_workspace_bytes(void);
+int mvp_gemm_streamk(const mvp_gemm_args*, void* stream);  /* what mvp_gemm_bias_act_res dispatches to for splitk == MVP_GEMM_STREAMK */
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm forward: fp32 rows [M, C] -> bf16 pair [M, C] (the next GEMM's A operand).

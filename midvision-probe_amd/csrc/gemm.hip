@@ -575,8 +575,11 @@ extern "C" int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits) {
 }
 
 // Diagnostic override (tools/gemm_bench.py): -DMVP_F_BM=.. -DMVP_F_BN=.. -DMVP_F_BK=.. -DMVP_F_ST=..
+extern "C" int mvp_gemm_streamk(const mvp_gemm_args* a, void* stream);  // gemm_sk.hip
+
 extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (!a || !a->a_hi || !a->w_hi) return MVP_EINVAL;
+  if (a->splitk == MVP_GEMM_STREAMK) return mvp_gemm_streamk(a, stream);
   if (a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & (a->conv ? 31 : 63))) {
     // the one non-conv exception: K % 32 == 0 through the BK = 32 two-stage tile (ResNet stem: K = 147 padded to 160)
     if (!(a && !a->conv && a->M > 0 && a->N > 0 && a->K > 0 && (a->K & 31) == 0 && a->precision == MVP_PREC_BF16X3 && a->splitk <= 1)) return MVP_EINVAL;

@@ -186,6 +186,8 @@ SYMBOLS = {
     "mvp_patch_gather": PatchGatherArgs,
     "mvp_gemm_bias_act_res": GemmArgs,
     "mvp_gemm_splitk_workspace_bytes": None,
+    "mvp_gemm_streamk_workspace_bytes": None,
+    "mvp_gemm_streamk": GemmArgs,
     "mvp_layernorm_fwd": LayerNormArgs,
     "mvp_attention_fwd": AttentionArgs,
     "mvp_cls_rows": ClsRowsArgs,
@@ -258,6 +260,8 @@ def load() -> C.CDLL:
     lib.mvp_metrics_breakdown_workspace_bytes.restype = _i64
     lib.mvp_metrics_workspace_bytes.argtypes = [_i]
     lib.mvp_metrics_workspace_bytes.restype = _i64
+    lib.mvp_gemm_streamk_workspace_bytes.argtypes = []
+    lib.mvp_gemm_streamk_workspace_bytes.restype = _i64
     lib.mvp_gemm_splitk_workspace_bytes.argtypes = [_i, _i, _i]
     lib.mvp_gemm_splitk_workspace_bytes.restype = _i64
     lib.mvp_gemm_tn_workspace_bytes.argtypes = [_i, _i, _i, _i, _i]

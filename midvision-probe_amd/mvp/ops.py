@@ -6,6 +6,7 @@ allocated by the caller (or by these helpers with torch.empty — plumbing only)
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -88,6 +89,26 @@ def splitk_auto(M: int, N: int, K: int) -> int:
     return 1
 
 
+_STREAMK_WS = {}  # device -> zero-initialised stream-K workspace (tile counters reset themselves; one stream at a time)
+_STREAMK_MODE = os.environ.get("MVP_STREAMK", "auto")  # "auto" | "0" | "1" (diagnostic override)
+
+
+def streamk_auto(M: int, N: int, K: int, precision: int) -> bool:
+    """Stream-K scheduling (csrc/gemm_sk.hip: 128x128x64 tiles, one workgroup per CU, equal k-iterations per CU) is OPT-IN
+    (MVP_STREAMK=1 or streamk=True).  Measured on MI355X (tools/gemm_bench.py --sk, bf16x3, us: tile kernel -> stream-K best
+    variant): B=16 qkv 39.8 -> 54.5, proj 20.3 -> 30.7, fc1 50.7 -> 69.1, fc2 61.5 -> 79.5; B=64 qkv 131 -> 170, fc2 169 -> 261.
+    One lock-stepped 8-wave workgroup per CU issues its LDS-DMA pieces (each costs the issuing wave 75-185 cycles) from far fewer
+    waves than five independent 64x64 workgroups do, and the partial-tile hand-over adds ~15 us per launch."""
+    return _STREAMK_MODE == "1"
+
+
+def _streamk_workspace(device) -> torch.Tensor:
+    ws = _STREAMK_WS.get(device)
+    if ws is None:
+        ws = _STREAMK_WS[device] = torch.zeros(int(lib.load().mvp_gemm_streamk_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
 def _splitk_workspace(M: int, N: int, S: int, device) -> torch.Tensor:
     need = int(lib.load().mvp_gemm_splitk_workspace_bytes(M, N, S))
     ws = _SPLITK_WS.get(device)
@@ -99,9 +120,10 @@ def _splitk_workspace(M: int, N: int, S: int, device) -> torch.Tensor:
 def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, out_f32=None, out: Optional[Pair] = None,
          act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
          row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0,
-         splitk: Optional[int] = None, residual_pair: Optional[Pair] = None) -> None:
+         splitk: Optional[int] = None, residual_pair: Optional[Pair] = None, streamk: Optional[bool] = None) -> None:
     """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off.
-    residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``."""
+    residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``.
+    streamk: None = automatic (streamk_auto), True / False force the stream-K kernel on / off."""
     o_hi, o_lo = out if out is not None else (None, None)
     args = lib.GemmArgs(
         lib.ptr(a[0]), lib.ptr(a[1]), lib.ptr(w[0]), lib.ptr(w[1]), lib.ptr(bias), lib.ptr(residual),
@@ -115,7 +137,12 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     if residual_pair is not None:
         args.residual_hi, args.residual_lo = lib.ptr(residual_pair[0]), lib.ptr(residual_pair[1])
     S = 1
-    if out_mask is None and not act_after_res and residual_pair is None:
+    plain = out_mask is None and not act_after_res and residual_pair is None
+    use_sk = plain and splitk is None and (streamk_auto(M, N, K, precision) if streamk is None else bool(streamk))
+    if use_sk:
+        ws = _streamk_workspace(a[0].device)
+        args.splitk, args.splitk_ws, args.splitk_ws_bytes = -1, lib.ptr(ws), ws.numel()
+    elif plain:
         S = splitk_auto(M, N, K) if splitk is None else int(splitk)
     if S > 1:
         ws = _splitk_workspace(M, N, S, a[0].device)
@@ -127,7 +154,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     e0.record()
     lib.call("mvp_gemm_bias_act_res", args)
     e1.record()
-    _TRACE.append(("gemm", gemm_tile(M, N, K, precision, S), precision, 2.0 * M * N * K, e0, e1))
+    _TRACE.append(("gemm", "streamk 128, 128, 64" if use_sk else gemm_tile(M, N, K, precision, S), precision, 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,

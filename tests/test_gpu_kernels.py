@@ -107,6 +107,56 @@ def test_gemm_splitk(dev, precision):
         ops.gemm(ap, wp, M, N, K, out_f32=torch.empty(M, N, device=dev), precision=pr, splitk=16)
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_gemm_streamk(dev, precision):
+    """Stream-K kernel (gemm_sk.hip): parity with fp64 on the four backbone shapes + ragged / tiny ones (M, N not multiples of
+    128; fewer k-iterations than CUs; a single tile), every epilogue form the backbone uses, bit-reproducible across launches,
+    shapes alternating on ONE workspace (tile counters must return to zero), and agreement with the tile-per-workgroup kernel."""
+    from mvp import lib, ops
+    from mvp.vit import parse_precision
+
+    pr = parse_precision(precision)
+    tol = 2e-5 if pr == lib.PREC_BF16 else 5e-5
+    cases = []
+    for (M, N, K) in ((3152, 2304, 768), (3152, 768, 768), (3152, 3072, 768), (3152, 768, 3072), (3136, 256, 3072), (777, 1280, 1024),
+                      (130, 72, 768), (64, 128, 64), (19216, 768, 768)):
+        g = torch.Generator().manual_seed(M + N + K)
+        a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+        bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ap, wp = ops.split_bf16(a.to(dev), pr), ops.split_bf16(w.to(dev), pr)
+        if pr == lib.PREC_BF16:
+            a, w = _bf16_round(a), _bf16_round(w)
+        ref = F.gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+        cases.append((M, N, K, ap, wp, bias.to(dev), res.to(dev), ref.numpy()))
+    outs = []
+    for rep in range(2):
+        for (M, N, K, ap, wp, bias, res, ref) in cases:
+            out = torch.full((M, N), float("nan"), device=dev)
+            op = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+            ops.gemm(ap, wp, M, N, K, bias=bias, residual=res, out_f32=out, out=op, act=lib.ACT_GELU, precision=pr, streamk=True)
+            torch.cuda.synchronize()
+            assert rel_l2(out.cpu().numpy(), ref) < tol, (M, N, K)
+            assert rel_l2((op[0].float() + op[1].float()).cpu().numpy(), ref) < tol + 2e-5
+            outs.append(out)
+    n = len(cases)
+    for i in range(n):
+        assert torch.equal(outs[i], outs[n + i]), "stream-K result must be bit-reproducible"
+    # in-place residual stream (x += proj(..)), as the ViT blocks use it, vs the tile kernel
+    M, N, K, ap, wp, bias, res, ref = cases[1]
+    x1, x2 = res.clone(), res.clone()
+    ops.gemm(ap, wp, M, N, K, bias=bias, residual=x1, out_f32=x1, precision=pr, streamk=True)
+    ops.gemm(ap, wp, M, N, K, bias=bias, residual=x2, out_f32=x2, precision=pr, streamk=False, splitk=1)
+    assert rel_l2(x1.cpu().numpy(), x2.cpu().numpy()) < 1e-6
+    # features the stream-K kernel does not carry are refused, not silently dropped
+    with pytest.raises(lib.MvpError):
+        a = lib.GemmArgs(ap[0].data_ptr(), ap[1].data_ptr() if ap[1] is not None else None, wp[0].data_ptr(), wp[1].data_ptr() if wp[1] is not None else None,
+                         None, None, x1.data_ptr(), None, None, M, N, K, K, K, N, N, N, 0, pr, 0, 0, 0, 0)
+        a.splitk, a.act_after_res = -1, 1
+        ws = ops._streamk_workspace(dev)
+        a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        lib.call("mvp_gemm_bias_act_res", a)
+
+
 def test_gemm_row_remap(dev):
     """Patch-embed form: rows written behind a CLS slot, pos-embed residual indexed mod hw."""
     from mvp import lib, ops

@@ -13,7 +13,7 @@ os.makedirs(OUT, exist_ok=True)
 
 def build(ablate, extra=""):
     so = os.path.join(OUT, f"libgemm_ab{ablate}{extra.replace(' ','').replace('-D','_').replace('=','')}.so")
-    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ABLATE={ablate} {extra} {CS}/gemm.hip -o {so}"
+    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ABLATE={ablate} {extra} {CS}/gemm.hip {CS}/gemm_sk.hip -o {so}"
     subprocess.run(cmd, shell=True, check=True)
     l = C.CDLL(so)
     l.mvp_gemm_bias_act_res.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
@@ -30,6 +30,9 @@ def main():
                 variants["%dx%dk%ds%dw%dn%d" % c] = cfg(*c)
             except Exception as e:
                 print("build failed", c)
+    if "--sk" in sys.argv:
+        variants = {"auto": variants["auto"], "streamk_spec": build(0, "-DMVP_SK_SPEC=1"), "streamk_il": build(0, "-DMVP_SK_SPEC=0 -DMVP_SK_DMA_INTERLEAVE=1"),
+                    "streamk_burst": build(0, "-DMVP_SK_SPEC=0 -DMVP_SK_DMA_INTERLEAVE=0")}
     if "--ablate" in sys.argv:
         variants.update({"no_load": build(2), "load_only": build(3), "epi_only": build(4)})
     dev = torch.device("cuda")
@@ -42,9 +45,15 @@ def main():
             args = lib.GemmArgs(a[0].data_ptr(), a[1].data_ptr(), w[0].data_ptr(), w[1].data_ptr(), bias.data_ptr(), None,
                                 None, out[0].data_ptr(), out[1].data_ptr(), m, n, k, k, k, n, n, n, 0, prec, 0, 0, 0, 0)
             st = torch.cuda.current_stream().cuda_stream
+            skws = ops._streamk_workspace(dev)
+            sk_args = lib.GemmArgs(a[0].data_ptr(), a[1].data_ptr(), w[0].data_ptr(), w[1].data_ptr(), bias.data_ptr(), None,
+                                   None, out[0].data_ptr(), out[1].data_ptr(), m, n, k, k, k, n, n, n, 0, prec, 0, 0, 0, 0)
+            sk_args.splitk, sk_args.splitk_ws, sk_args.splitk_ws_bytes = -1, skws.data_ptr(), skws.numel()
+            base_args = args
             res = {}
             for rnd in range(3):
                 for vn, l in variants.items():
+                    args = sk_args if vn.startswith("streamk") else base_args
                     for _ in range(3): l.mvp_gemm_bias_act_res(C.byref(args), st)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
