@@ -29,19 +29,41 @@ for _p in (REPO, os.path.join(REPO, "midvision-probe_amd")):
 import torch  # noqa: E402
 
 
+def _latest_profile(suffix: str):
+    """Newest committed profiles/rNN_<suffix> (the PMC passes cannot run inside the timed process: rocprofv3 wraps it)."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r[0-9][0-9]_{suffix}")))
+    return paths[-1] if paths else None
+
+
 def pmc_traffic(kernel: str):
-    """Memory-side bytes per launch of `kernel` from the committed PMC passes (rocprofv3 cannot run inside the timed
-    process): profiles/r01_pmc_traffic.json, collected on the default workload and corrected as MI355X_MICROARCH.md
-    prescribes for gfx950.  None when no entry matches."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """(memory-side bytes per launch of `kernel`, source file) from the newest committed PMC pass over this same default
+    workload (tools/make_profiles.py), corrected as MI355X_MICROARCH.md prescribes for gfx950.  (None, None) if absent."""
+    path = _latest_profile("pmc_traffic.json")
     try:
         with open(path) as f:
             per = json.load(f)["per_launch"]
-    except (OSError, ValueError, KeyError):
-        return None
+    except (OSError, ValueError, KeyError, TypeError):
+        return None, None
     for k, v in per.items():
         if k.startswith(kernel.rstrip(">")):
-            return v["hbm_bytes"]
+            return v["hbm_bytes"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    return None, None
+
+
+def pmc_mfma_busy(kernel: str):
+    """SQ_VALU_MFMA_BUSY_CYCLES per launch of `kernel` from the newest committed profiles/rNN_pmc_summary.txt, or None."""
+    import re
+
+    path = _latest_profile("pmc_summary.txt")
+    try:
+        for line in open(path):
+            if line.startswith(kernel.rstrip(">")):
+                m = re.search(r"SQ_VALU_MFMA_BUSY_CYCLES=([0-9.e+]+)", line)
+                return float(m.group(1)) if m else None
+    except (OSError, TypeError):
+        return None
     return None
 
 
@@ -57,6 +79,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-oracle steps (~1.8 s each at B=16 on 16 cores: ~11 s bounded sample)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sustained-steps", type=int, default=300, help="extra untimed-by-the-contract leg: the same step for this many more iterations (steady-state clocks); 0 = skip")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
 
@@ -172,21 +195,38 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    loss_acc = torch.zeros((), device=dev)
+    losses = []  # device scalars, reduced after the timed region (no accumulate kernel inside it, no host sync per step)
     for i in range(args.warmup):
-        loss_acc += step(i)
+        losses.append(step(i))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss_acc += step(args.warmup + i)
+        losses.append(step(args.warmup + i))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
-    last_loss = float(loss_acc.item()) / max(args.warmup + args.steps, 1)
+    last_loss = float(torch.stack(losses).mean().item())
+    loss_acc = torch.zeros((), device=dev)
     images_per_s = world * B * args.steps / dt
+
+    # ---------------- sustained leg (reported next to `value`, never instead of it): a short run sits in boost clocks
+    sustained = None
+    if args.sustained_steps > 0:
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.sustained_steps):
+            step(args.warmup + args.steps + i)
+        barrier()
+        sdt = time.perf_counter() - t1
+        if world > 1:
+            tm = torch.tensor([sdt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            sdt = float(tm.item())
+        sustained = {"steps": args.sustained_steps, "value": round(world * B * args.sustained_steps / sdt, 2), "unit": "images/s",
+                     "ms_per_step": round(sdt / args.sustained_steps * 1e3, 4)}
 
     # ---------------- optional PCIe-inclusive leg (never `value`): the same steps fed from HOST memory
     h2d = None
@@ -239,10 +279,10 @@ def main():
         barrier()
         ops.set_trace(None)
     if not args.no_roofline and rank == 0:
-        groups = {}
+        groups, hbm = {}, {}
         for kind, tile, prec, flops, e0, e1 in trace:
             key = (kind, tile)
-            gsum = groups.setdefault(key, [0.0, 0.0, 0])
+            gsum = (hbm if kind == "hbm" else groups).setdefault(key, [0.0, 0.0, 0])
             gsum[0] += flops
             gsum[1] += e0.elapsed_time(e1) * 1e-3
             gsum[2] += 1
@@ -251,10 +291,18 @@ def main():
         (kind, tile), (fl, sec, cnt) = dom
         achieved = fl / sec / 1e12
         name = f"gemm_kernel<{tile}>" if kind == "gemm" else "attention_kernel"
-        traffic = pmc_traffic(name) if (B, H, W, args.precision, args.probe) == (16, 224, 224, "bf16x3", "linear") else None
+        default_wl = (B, H, W, args.precision, args.probe) == (16, 224, 224, "bf16x3", "linear")
+        traffic, traffic_src = pmc_traffic(name) if default_wl else (None, None)
+        busy = pmc_mfma_busy(name) if default_wl else None
+        clk = 2.1e9  # clock the chip holds under this load (in-kernel s_memtime / s_memrealtime)
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-            "traffic": traffic, "traffic_unit": "bytes/launch (memory-side, rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+            "traffic": traffic, "traffic_unit": f"bytes/launch (memory-side, rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE; committed pass {traffic_src})",
+            "mfma_busy": None if busy is None else {"SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy,
+                                                    "frac_of_simd_cycles": round(busy / (1024 * (sec / cnt) * clk), 3),
+                                                    "note": "committed PMC pass; 1024 SIMDs x live launch duration x 2.1 GHz"},
+            "hbm_kernels": {k[1]: {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2), "alg_mbytes_per_launch": round(v[0] / v[2] / 1e6, 2),
+                                   "achieved_gbps": round(v[0] / v[1] / 1e9, 1), "frac_of_8TBps": round(v[0] / v[1] / 8e12, 3)} for k, v in hbm.items()},
             "kernel": name, "launches_per_step": cnt // nrep, "avg_launch_us": round(sec / cnt * 1e6, 2),
             "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop); HIP events on the launch stream",
@@ -284,6 +332,27 @@ def main():
         cpu = {"value": round(Bc * args.cpu_steps / cdt, 3), "unit": "images/s", "cores": cores, "kind": "port",
                "sample": f"{args.cpu_steps} steps of B={Bc} {H}x{W} (same step: extract 4 taps + linear bindepth probe + DepthLoss + backward + AdamW), 1 warm-up step, torch {torch.__version__} CPU fp32"}
 
+    # ---------------- BASELINE config #1 (CPU-only by definition): DINO ResNet-50 random-init, single last-stage tap, 8 x 224 x 224
+    # -> internally resized to 480^2 -> [8, 2048, 15, 15]; the oracle port of that path on the host cores, bounded sample
+    cpu1 = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1 and args.probe == "linear" and (H, W) == (224, 224):
+        from oracle import resnet as ores
+
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        rsd = ores.make_resnet50_weights(seed=0)
+        g1 = torch.Generator().manual_seed(0)
+        imgs = torch.randn(8, 3, 224, 224, generator=g1)
+        with torch.no_grad():
+            ores.resnet_dense_features(rsd, imgs, [4], fixed_size=480)  # warm-up
+            t0 = time.perf_counter()
+            n1 = 3
+            for _ in range(n1):
+                f4 = ores.resnet_dense_features(rsd, imgs, [4], fixed_size=480)
+            c1dt = time.perf_counter() - t0
+        cpu1 = {"value": round(8 * n1 / c1dt, 3), "unit": "images/s", "cores": cores, "kind": "port", "output_shape": list(f4.shape),
+                "sample": f"{n1} forward passes of DINO ResNet-50 (random-init, single tap, add_norm) on 8x224x224 -> 480^2, 1 warm-up, torch {torch.__version__} CPU fp32"}
+
     if rank == 0:
         out = {
             "metric": "images/sec feature-extract+probe-step, ViT-B/16 224^2" if (H, W) == (224, 224) else f"images/sec feature-extract+probe-step, ViT-B/16 {H}x{W}",
@@ -296,7 +365,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
                        "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
             "mean_loss": round(last_loss, 5),
-            "roofline": roofline, "cpu_baseline": cpu, **({"h2d_inclusive": h2d} if h2d else {}),
+            "sustained": sustained,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, **({"h2d_inclusive": h2d} if h2d else {}),
         }
         print(json.dumps(out))
     if world > 1:

@@ -211,6 +211,7 @@ typedef struct {
   int mode;
   float* cls_out;       /* [B, C] fp32 or NULL: the normalised FIRST token of each image (the CLS token that
                            tokens_to_output(output="cls" / "dense-cls") returns, utils.py:105-124); needs N > hw */
+  int64_t* num_batches_tracked; /* or NULL: BatchNorm's step counter, incremented in train mode (mode 0) by the statistics kernel */
 } mvp_bn_tokens_args;
 int64_t mvp_bn_tokens_workspace_bytes(int M, int C);
 int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args*, void* stream);

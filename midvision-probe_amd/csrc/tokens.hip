@@ -170,6 +170,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_a
   const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
   ss[c] = rstd * g;
   ss[p.C + c] = b - (float)mean * rstd * g;
+  if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;  // nn.BatchNorm train-mode bookkeeping, no extra launch
 }
 
 // eval (running stats) / identity modes: scale & shift without a statistics pass.

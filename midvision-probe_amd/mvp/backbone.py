@@ -201,7 +201,8 @@ class ViTBackbone(nn.Module):
     def _tap_bn(self):
         if not self.add_norm:
             return None, 2
-        bns = [dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var) for bn in self.batchnorms]
+        bns = [dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var,
+                    num_batches_tracked=bn.num_batches_tracked) for bn in self.batchnorms]
         return bns, (0 if self.training else 1)
 
     def _extract(self, images: torch.Tensor, n_spatial_from_grid: bool = True, want_cls: bool = False):
@@ -212,8 +213,7 @@ class ViTBackbone(nn.Module):
         with torch.no_grad():
             taps = eng.forward_taps(images, self.multilayers, bn=bns, bn_mode=mode, tap_input_of_block=self.tap_input_of_block,
                                     want_cls=want_cls or self.output in ("cls", "dense-cls"))
-            if self.add_norm and self.training:
-                torch._foreach_add_([bn.num_batches_tracked for bn in self.batchnorms], 1)  # one launch for all taps
+            # (num_batches_tracked is incremented by the tap kernel's statistics pass: no extra launch)
         return taps
 
     def _finish(self, taps: TapOutputs):

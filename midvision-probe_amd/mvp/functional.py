@@ -98,7 +98,15 @@ def pack_features(feats: Sequence[torch.Tensor], precision: int) -> PackedFeatur
     return pack
 
 
-def _head_weight_grad(gl0: torch.Tensor, K: int, pack: PackedFeatures, pr: int) -> torch.Tensor:
+def _grad_dst(param, shape):
+    """The parameter's slot in FlatAdamW's flat gradient buffer as a fresh [shape] view, or None (plain torch optimisers)."""
+    from .optim import grad_destination
+
+    d = grad_destination(param) if param is not None else None
+    return d.view(shape) if d is not None and d.numel() == int(torch.Size(shape).numel()) else None
+
+
+def _head_weight_grad(gl0: torch.Tensor, K: int, pack: PackedFeatures, pr: int, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[K, Ctot] = gl0ᵀ · F over the token axis: TN split-K kernel on the row-major gradient and the packed features
     (the weight gradient of the 1x1 conv, probes.py:431)."""
     from . import conv
@@ -109,7 +117,7 @@ def _head_weight_grad(gl0: torch.Tensor, K: int, pack: PackedFeatures, pr: int) 
         gpad[:, :K] = gl0
         gl0 = gpad
     gp = ops.split_bf16(gl0, pr)
-    dW = torch.empty(K, pack.Cpad, dtype=torch.float32, device=dev)
+    dW = dst if (dst is not None and pack.Cpad == pack.Ctot and tuple(dst.shape) == (K, pack.Cpad)) else torch.empty(K, pack.Cpad, dtype=torch.float32, device=dev)
     geo = dict(B=pack.B, H=pack.h, W=pack.w, C=pack.Cpad, Ho=pack.h, Wo=pack.w, kh=1, kw=1, stride=1, pad=0, up=0)
     conv.conv_dw(gp, Kg, pack.tok, pack.Cpad, geo, K, dW, precision=pr)
     return dW[:, :pack.Ctot]
@@ -191,6 +199,7 @@ class _LinearBinsHead(torch.autograd.Function):
         lib.call("mvp_linear_bins_fwd", a)
         ctx.pack, ctx.precision, ctx.cfg = pack, precision, (K, min_depth, max_depth)
         ctx.wshape, ctx.generation = weight.shape, pack.generation
+        ctx.params = (weight, bias)
         ctx.save_for_backward(depth, inv, gate)
         return depth
 
@@ -207,8 +216,11 @@ class _LinearBinsHead(torch.autograd.Function):
         gl0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
         a = lib.LinearBinsArgs(None, lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), lib.ptr(gd.contiguous().float()), lib.ptr(gl0), B, h, w, K, 4, mn, mx)
         lib.call("mvp_linear_bins_bwd", a)
-        dW = _head_weight_grad(gl0, K, pack, pr)
-        db = torch.empty(K, dtype=torch.float32, device=dev)
+        wparam, bparam = ctx.params
+        dW = _head_weight_grad(gl0, K, pack, pr, dst=_grad_dst(wparam, (K, Ctot)))
+        db = _grad_dst(bparam, (K,))
+        if db is None:
+            db = torch.empty(K, dtype=torch.float32, device=dev)
         ops.colsum(gl0, db, pack.M, K)
         return dW.reshape(ctx.wshape), db, None, None, None, None, None
 
@@ -313,6 +325,29 @@ def depth_sigmoid(logits_cl, min_depth, max_depth):
 
 
 # --------------------------------------------------------------------------- losses
+_ONE = {}
+
+
+def _one(dev) -> torch.Tensor:
+    t = _ONE.get(dev)
+    if t is None:
+        t = _ONE[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
+def backward(loss: torch.Tensor) -> None:
+    """``loss.backward()`` with a cached device scalar 1 as the root gradient: no ones_like fill, and the loss Functions
+    recognise it and hand their stored gradient on without a multiply kernel."""
+    torch.autograd.backward(loss, grad_tensors=_one(loss.device))
+
+
+def _scaled(grad: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    one = _ONE.get(g.device)
+    if one is not None and g.data_ptr() == one.data_ptr():
+        return grad
+    return grad * g
+
+
 class _DepthLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, w_sig, w_grad, max_depth):
@@ -333,7 +368,7 @@ class _DepthLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None, None
+        return _scaled(grad, g), None, None, None, None
 
 
 def depth_loss(pred, target, w_sig=10.0, w_grad=0.5, max_depth=10.0):
@@ -358,7 +393,7 @@ class _AngularLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return grad * g, None, None, None
+        return _scaled(grad, g), None, None, None
 
 
 def angular_loss(pred, gt, mask, uncertainty_aware=False, eps=1e-4):

@@ -73,7 +73,7 @@ class BnTokensArgs(C.Structure):
                 ("nchw", _vp), ("tok_hi", _vp), ("tok_lo", _vp), ("ld_tok", _i), ("col_off", _i),
                 ("tokT_hi", _vp), ("tokT_lo", _vp), ("ldT", _i),
                 ("workspace", _vp), ("workspace_bytes", _i64),
-                ("B", _i), ("N", _i), ("C", _i), ("hw", _i), ("eps", _f), ("momentum", _f), ("mode", _i), ("cls_out", _vp)]
+                ("B", _i), ("N", _i), ("C", _i), ("hw", _i), ("eps", _f), ("momentum", _f), ("mode", _i), ("cls_out", _vp), ("num_batches_tracked", _vp)]
 
 
 class PackNchwArgs(C.Structure):

@@ -26,6 +26,19 @@ def set_trace(lst) -> None:
     _TRACE = lst
 
 
+def _traced(kind: str, tile: str, precision: int, work: float, fn) -> None:
+    """Run ``fn`` bracketed by HIP events on the launch stream when bench.py has installed a trace list
+    (``work`` = algorithmic flops for MFMA-bound kernels, algorithmic HBM bytes for memory-bound ones)."""
+    if _TRACE is None:
+        fn()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    _TRACE.append((kind, tile, precision, work, e0, e1))
+
+
 def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: int = 1) -> str:
     """Mirror of the tile choice in csrc/gemm.hip -> template arguments BM,BN,BK,SPLIT,NSTAGE."""
     if splitk > 1:
@@ -160,7 +173,9 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,
               out_f32: Optional[torch.Tensor] = None) -> None:
     a = lib.LayerNormArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(out[0]), lib.ptr(out[1]), lib.ptr(out_f32), M, Cdim, eps)
-    lib.call("mvp_layernorm_fwd", a)
+    # algorithmic HBM bytes: the fp32 row read once + the bf16 pair (or single bf16) written once
+    nb = M * Cdim * (4 + 2 * (2 if out[1] is not None else 1) + (4 if out_f32 is not None else 0))
+    _traced("hbm", "layernorm_kernel", 0, float(nb), lambda: lib.call("mvp_layernorm_fwd", a))
 
 
 def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None) -> None:
@@ -186,13 +201,17 @@ def bn_tokens_workspace_bytes(M: int, Cdim: int) -> int:
 
 def bn_tokens_to_nchw(x, B, N, Cdim, hw, *, workspace, stats=None, gamma=None, beta=None, running_mean=None, running_var=None,
                       nchw=None, tok: Optional[Pair] = None, ld_tok=0, col_off=0, tokT: Optional[Pair] = None, ldT=0,
-                      eps=1e-5, momentum=0.1, mode=0, cls_out=None) -> None:
+                      eps=1e-5, momentum=0.1, mode=0, cls_out=None, num_batches_tracked=None) -> None:
     t_hi, t_lo = tok if tok is not None else (None, None)
     tt_hi, tt_lo = tokT if tokT is not None else (None, None)
     a = lib.BnTokensArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(running_mean), lib.ptr(running_var), lib.ptr(stats),
                          lib.ptr(nchw), lib.ptr(t_hi), lib.ptr(t_lo), ld_tok, col_off, lib.ptr(tt_hi), lib.ptr(tt_lo), ldT,
-                         lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode, lib.ptr(cls_out))
-    lib.call("mvp_bn_tokens_to_nchw_fwd", a)
+                         lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode, lib.ptr(cls_out),
+                         lib.ptr(num_batches_tracked) if mode == 0 else None)
+    # algorithmic HBM bytes: x read twice in train mode (statistics, apply), NCHW fp32 + token-major pair written
+    M = B * N
+    nb = M * Cdim * 4 * (2 if mode == 0 else 1) + B * hw * Cdim * ((4 if nchw is not None else 0) + (4 if tok is not None and tok[1] is not None else (2 if tok is not None else 0)))
+    _traced("hbm", "bn_tokens (partial+finalize+apply)", 0, float(nb), lambda: lib.call("mvp_bn_tokens_to_nchw_fwd", a))
 
 
 def pack_nchw_tokens(nchw: torch.Tensor, B: int, Cdim: int, hw: int, *, tok: Optional[Pair] = None, ld_tok=0, col_off=0,
@@ -227,7 +246,8 @@ def depth_loss_workspace_bytes(B: int, HW: int) -> int:
 def depth_loss(pred, target, loss, grad_pred, workspace, B, HW, w_sig=10.0, w_grad=0.5, max_depth=10.0, eps=1e-3, sigma=0.85) -> None:
     a = lib.DepthLossArgs(lib.ptr(pred), lib.ptr(target), lib.ptr(loss), lib.ptr(grad_pred), lib.ptr(workspace),
                           workspace.numel() * workspace.element_size(), B, HW, w_sig, w_grad, max_depth, eps, sigma)
-    lib.call("mvp_depth_loss_fwd_bwd", a)
+    # algorithmic HBM bytes: pred + target read, gradient written (one pass each)
+    _traced("hbm", "depth_loss (dl_stats+dl_pairs+dl_finalize+dl_grad)", 0, float(B * HW * 12), lambda: lib.call("mvp_depth_loss_fwd_bwd", a))
 
 
 def angular_loss(pred, gt, mask_u8, loss, grad_pred, workspace, B, Cp, HW, eps=1e-4) -> None:

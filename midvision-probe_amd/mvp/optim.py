@@ -16,6 +16,23 @@ import torch
 from . import ops
 
 
+# parameter id -> (flat gradient buffer, element offset, numel, shape): lets the probe-head backward kernels write a gradient
+# straight into its slot of the flat buffer (no zero-fill before, no accumulate-add / copy after: see FlatAdamW.zero_grad)
+_GRAD_DST = {}
+
+
+def grad_destination(param: torch.Tensor):
+    """A FRESH view of ``param``'s slot in its optimiser's flat gradient buffer, or None.  A backward that returns this very tensor
+    lets autograd adopt it as ``param.grad`` (it steals a gradient it holds the only reference to), so the gradient never moves."""
+    ent = _GRAD_DST.get(id(param))
+    if ent is None:
+        return None
+    flat, off, n, shape, ref = ent
+    if ref() is not param:  # id reuse after the parameter died
+        return None
+    return flat[off:off + n].view(shape)
+
+
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, process_group=None,
                  overlap_comm: bool = False, broadcast_init: bool = True):
@@ -48,6 +65,12 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.data = self.flat_param[off:off + n].view(p.shape)
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
                 off += sz
+        import weakref
+
+        off = 0
+        for p, sz in zip(plist, sizes):
+            _GRAD_DST[id(p)] = (self.flat_grad, off, p.numel(), tuple(p.shape), weakref.ref(p))
+            off += sz
         self._params = plist
         self._n = total
         self._step = 0
@@ -62,23 +85,24 @@ class FlatAdamW(torch.optim.Optimizer):
 
             dist.broadcast(self.flat_param, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Zero the flat gradient IN PLACE (the .grad views must survive: autograd accumulates into them)."""
-        self.flat_grad.zero_()
-        off = 0
+    def zero_grad(self, set_to_none: bool = True):
+        """Drop the .grad references instead of zero-filling the flat buffer: every probe parameter receives a full gradient each
+        step, which the head kernels write straight into the flat buffer (grad_destination) or which step() copies there; a
+        parameter that received none has its slot zeroed in step().  No fill kernel, no accumulate-add kernels."""
         for p in self._params:
-            n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + off * 4:
-                p.grad = self.flat_grad[off:off + n].view(p.shape)
-            off += (n + 3) // 4 * 4
+            p.grad = None
 
     def _gather_stray_grads(self):
-        """autograd replaces .grad when it was None at backward time; fold such tensors back."""
+        """Bring every gradient into its slot of the flat buffer: already there (written in place by the kernels) -> nothing;
+        elsewhere (generic autograd path, e.g. the DPT head) -> one copy; absent -> zero the slot."""
         off = 0
         for p in self._params:
             n = p.numel()
             want = self.flat_grad.data_ptr() + off * 4
-            if p.grad is not None and p.grad.data_ptr() != want:
+            if p.grad is None:
+                self.flat_grad[off:off + n].zero_()
+                p.grad = self.flat_grad[off:off + n].view(p.shape)
+            elif p.grad.data_ptr() != want:
                 self.flat_grad[off:off + n].copy_(p.grad.reshape(-1))
                 p.grad = self.flat_grad[off:off + n].view(p.shape)
             off += (n + 3) // 4 * 4

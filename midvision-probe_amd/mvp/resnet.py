@@ -128,7 +128,8 @@ class ResNetEngine:
                 ops.bn_tokens_to_nchw(xF, B, HW, C, HW, workspace=ws, stats=stats,
                                       gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                                       running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
-                                      nchw=nchw, tok=tok, ld_tok=C, col_off=0, mode=bn_mode)
+                                      nchw=nchw, tok=tok, ld_tok=C, col_off=0, mode=bn_mode,
+                                      num_batches_tracked=b.get("num_batches_tracked") if b else None)
                 outs.append(nchw)
                 outs.tokens.append(tok)
                 outs.dims.append((C, H, W))

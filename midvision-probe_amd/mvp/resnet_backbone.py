@@ -119,11 +119,10 @@ class ResNetBackbone(nn.Module):
             x = self._resize(x)
             bns, mode = None, 2
             if self.add_norm:
-                bns = [dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var) for bn in self.batchnorms]
+                bns = [dict(weight=bn.weight, bias=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var,
+                            num_batches_tracked=bn.num_batches_tracked) for bn in self.batchnorms]
                 mode = 0 if self.training else 1
             outs = self.engine().forward_taps(x, self.multilayers, bn=bns, bn_mode=mode)
-            if self.add_norm and self.training:
-                torch._foreach_add_([self.batchnorms[i].num_batches_tracked for i in self.multilayers], 1)
         return outs[0] if len(outs) == 1 else outs
 
 

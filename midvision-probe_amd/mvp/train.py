@@ -47,7 +47,7 @@ def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target
 
         pred = match_scale_and_shift(pred, target, clamp=(0.001, 1.0))
     loss = loss_fn(pred, target)
-    loss.backward()
+    MF.backward(loss)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
@@ -65,7 +65,7 @@ def train_snorm_step(model, probe, optimizer, scheduler, images, target, mask, d
     pred = MF.interpolate(pred.contiguous(), size=target.shape[-2:], mode="bicubic")
     uncertainty = pred.shape[1] > 3
     loss = angular_loss(pred, target, mask, uncertainty_aware=uncertainty)
-    loss.backward()
+    MF.backward(loss)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()

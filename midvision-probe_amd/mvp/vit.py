@@ -240,7 +240,7 @@ class ViTEngine:
                 gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                 running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                 nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
-                mode=bn_mode, cls_out=cls)
+                mode=bn_mode, cls_out=cls, num_batches_tracked=b.get("num_batches_tracked") if b else None)
             outs.append(nchw)
 
         last = max(layers)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of one round on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh r02            -> gpurun_out/<tag>_{stats,pmc_fetch,pmc_write,pmc_sq,pmc_tcc}/ , then
+#   python tools/make_profiles.py <tag> ... copies the summaries into profiles/ (tracked).
+# Counters are collected in their own passes with --kernel-trace only (never with sys/hip/hsa tracing), one group per pass
+# (MI355X_MICROARCH.md "rocprofv3 PMC slots": SQ 8 slots, TCC 4; FETCH_SIZE and WRITE_SIZE do not fit one pass).
+set -eo pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+ARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 7 --warmup 3"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT \
+  --output-format csv -d $OUT/${TAG}_pmc_sq -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/${TAG}_pmc_tcc -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_tcc.log 2>&1
+cd $ROOT
+python3 tools/make_profiles.py $TAG $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_tcc > $OUT/${TAG}_make_profiles.log 2>&1 || true
+mkdir -p $OUT/${TAG}_profiles && cp profiles/${TAG}_* $OUT/${TAG}_profiles/ 2>/dev/null || true
+echo "profile passes done: $(ls $OUT | grep ${TAG}_ | wc -l) entries"
