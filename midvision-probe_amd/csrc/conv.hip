@@ -157,14 +157,15 @@ __global__ __launch_bounds__(256) void maxpool_cl_kernel(const mvp_maxpool_cl_ar
 // into dW's [i][tap][j] rows.
 // NW waves per workgroup: 4 (2x2 wave grid, 64x64 per wave) or 8 (4x2, 32(j) x 64(i) per wave: same tile and LDS, more
 // waves per SIMD to hide the staging latency).
-template <int SPLIT, int NST, int NW = 4>
+// KT = pixels per K-tile (32 or 64): 64 halves the barriers and LDS-DMA waits per MFMA (one stage = 64 KB in bf16x3).
+template <int SPLIT, int NST, int NW = 4, int KT = 32>
 __global__ __launch_bounds__(NW * 64) void gemm_tn_conv_kernel(const mvp_gemm_tn_args p) {
-  constexpr int RPW = 32 / NW;   // pixel rows of a K-tile staged by one wave (8 or 4)
+  constexpr int RPW = KT / NW;   // pixel rows of a K-tile staged by one wave
   constexpr int WJ = 256 / NW;   // j (input-channel) extent of a wave tile: 64 or 32
   constexpr int JT = WJ / 16;    // 16-wide j sub-tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
-  constexpr int TILE = 32 * 256;             // one [32][128] bf16 image
+  constexpr int TILE = KT * 256;             // one [KT][128] bf16 image
   constexpr int STAGE = 2 * NARR * TILE;     // G (hi[,lo]) then X (hi[,lo])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g4 = lane >> 4, c16 = lane & 15;
@@ -179,10 +180,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_conv_kernel(const mvp_gemm_tn
   const int ti = bid / tiles_j, tj = bid - ti * tiles_j;
   const int tap = tj / jt_per_tap, c0 = (tj - tap * jt_per_tap) * 128, i0 = ti * 128;
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
-  // pixel range of this split (multiple of 32)
-  const int64_t per = ((p.M + p.splits - 1) / p.splits + 31) / 32 * 32;
+  // pixel range of this split (multiple of KT)
+  const int64_t per = ((p.M + p.splits - 1) / p.splits + KT - 1) / KT * KT;
   const int64_t mbeg = (int64_t)split * per, mend = min<int64_t>(p.M, mbeg + per);
-  const int nk = (mend > mbeg) ? (int)((mend - mbeg + 31) / 32) : 0;
+  const int nk = (mend > mbeg) ? (int)((mend - mbeg + KT - 1) / KT) : 0;
   const int Hs = p.H >> p.up, Ws = p.W >> p.up;
 
   // staging: a piece = 4 rows x 256 B; wave w stages rows w*8 .. w*8+7 (two pieces)
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_conv_kernel(const mvp_gemm_tn
 #pragma unroll
     for (int ps = 0; ps < RPW / 4; ++ps) {
       const int r = wave * RPW + ps * 4 + rsub;    // tile row (pixel)
-      const int64_t m = mbeg + (int64_t)kt * 32 + r;
+      const int64_t m = mbeg + (int64_t)kt * KT + r;
       const int cs = (c16 ^ (fsw(r) << 1)) << 3;   // swizzled source chunk (elements)
       const bool inr = m < mend;
       // G row
@@ -242,7 +243,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_conv_kernel(const mvp_gemm_tn
 
   auto mma_tile = [&](const char* gb) {
     const char* xb = gb + NARR * TILE;
-    const int r0 = g4 * 8 + q;
+#pragma unroll
+    for (int ks = 0; ks < KT / 32; ++ks) {
+    const int r0 = ks * 32 + g4 * 8 + q;
     bf16x8_t xf_hi[JT], xf_lo[JT], gf_hi[4], gf_lo[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_conv_kernel(const mvp_gemm_tn
         }
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf_hi[a], gf_hi[b], acc[a][b], 0, 0, 0);
       }
+    }
   };
   if (NST == 1) {
     // one LDS stage (32 KB): up to 4-5 workgroups resident per CU overlap each other's load and MFMA phases
@@ -338,16 +342,16 @@ inline int grid_for(int64_t work, int cap = 4096) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-template <int SPLIT, int NST, int NW = 4>
+template <int SPLIT, int NST, int NW = 4, int KT = 32>
 int launch_tn(const mvp_gemm_tn_args* a, hipStream_t s) {
-  constexpr int SMEM = NST * 2 * ((SPLIT == 3) ? 2 : 1) * 32 * 256;
+  constexpr int SMEM = NST * 2 * ((SPLIT == 3) ? 2 : 1) * KT * 256;
   static int configured = [] {
-    return (int)hipFuncSetAttribute((const void*)gemm_tn_conv_kernel<SPLIT, NST, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    return (int)hipFuncSetAttribute((const void*)gemm_tn_conv_kernel<SPLIT, NST, NW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int T = a->kh * a->kw;
   const int blocks = a->splits * ((a->Cout + 127) / 128) * T * (a->Cin / 128);
-  hipLaunchKernelGGL((gemm_tn_conv_kernel<SPLIT, NST, NW>), dim3(blocks), dim3(NW * 64), SMEM, s, *a);
+  hipLaunchKernelGGL((gemm_tn_conv_kernel<SPLIT, NST, NW, KT>), dim3(blocks), dim3(NW * 64), SMEM, s, *a);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for((int64_t)a->Cout * a->Cin * T)), dim3(256), 0, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
@@ -399,8 +403,12 @@ extern "C" int mvp_gemm_tn_conv(const mvp_gemm_tn_args* a, void* stream) {
   if ((a->ldg & 7) || (a->ldx & 7) || a->ldx < a->Cin || a->ldg < ((a->Cout + 127) / 128) * 128) return MVP_EINVAL;
   if (a->precision == MVP_PREC_BF16X3) {
     if (!a->g_lo || !a->x_lo) return MVP_EINVAL;
-    // one LDS stage (+1.3 % over two on the DPT step) and 8 waves on the 128x128 tile (+5 %: 618 -> 649 img/s)
-    return launch_tn<3, 1, 8>(a, (hipStream_t)stream);
+    // one LDS stage (+1.3 % over two on the DPT step) and 8 waves on the 128x128 tile (+5 %: 618 -> 649 img/s);
+    // 64-pixel K-tiles: half the barriers / LDS-DMA waits per MFMA of the 32-pixel form (tools/tn_bench.py, DPT conv shapes: +2...13 %)
+#ifndef MVP_TN_KT
+#define MVP_TN_KT 64
+#endif
+    return launch_tn<3, 1, 8, MVP_TN_KT>(a, (hipStream_t)stream);
   }
   if (a->precision != MVP_PREC_BF16) return MVP_EINVAL;
   return launch_tn<1, 2>(a, (hipStream_t)stream);

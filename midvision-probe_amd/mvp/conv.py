@@ -61,14 +61,27 @@ def conv_gemm(x: Pair, g: dict, wk: Pair, N: int, *, bias=None, act=lib.ACT_NONE
     lib.call("mvp_gemm_bias_act_res", args)
 
 
+def tn_splits(tiles: int, M: int) -> int:
+    """Split-K factor of the TN weight-gradient kernel.  One 64-pixel stage is 64 KB of LDS, so 2 workgroups are resident per CU
+    (512 slots): pick the number of rounds R in 1..4 and S = 512 R / tiles that minimise R x (k-tiles per block + fixed cost).
+    Measured (tools/tn_bench.py, us, old rule -> this rule): 512->512 @28^2 223 -> 197, @64^2 511 -> 458, 256->256 @56^2 232 -> 185."""
+    best, best_cost = 1, None
+    for R in (1, 2, 3, 4):
+        S = max(1, min(64, (512 * R) // max(tiles, 1), max(1, M // 256)))
+        cost = R * ((M + S * 64 - 1) // (S * 64) + 6)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = S, cost
+    return best
+
+
 def conv_dw(gp: Pair, ldg: int, x: Pair, ldx: int, g: dict, Cout: int, dw: torch.Tensor, *, accumulate=False, precision=PREC_BF16X3,
             splits: Optional[int] = None) -> None:
     """dw[Cout, C, kh, kw] (+)= sum_m G[m, :Cout]ᵀ · im2col(x)[m]   (TN GEMM over pixels, split-K)."""
     M = g["B"] * g["Ho"] * g["Wo"]
     T = g["kh"] * g["kw"]
     tiles = ((Cout + 127) // 128) * T * (g["C"] // 128)
-    if splits is None:  # ~2-4 workgroups per CU, at least 32 pixels' worth of K per split
-        splits = max(1, min(64, (768 + tiles - 1) // tiles, (M + 511) // 512))
+    if splits is None:
+        splits = tn_splits(tiles, M)
     ws = torch.empty(int(lib.load().mvp_gemm_tn_workspace_bytes(Cout, g["C"], g["kh"], g["kw"], splits)) // 4, dtype=torch.float32, device=dw.device)
     a = lib.GemmTnArgs(lib.ptr(gp[0]), lib.ptr(gp[1]), lib.ptr(x[0]), lib.ptr(x[1]), lib.ptr(ws), lib.ptr(dw), lib.ptr(zero_page(dw.device)),
                        M, Cout, g["C"], ldg, ldx, g["H"], g["W"], g["Ho"], g["Wo"], g["kh"], g["kw"], g["stride"], g["pad"], g["up"],

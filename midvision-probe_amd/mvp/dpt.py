@@ -112,6 +112,7 @@ class _DPTViT(torch.autograd.Function):
         ctx.pack, ctx.pr, ctx.dims = pack, pr, (B, h, w, C, Hd, k, Cout, K4)
         ctx.saved_rcu, ctx.o0P, ctx.h0P, ctx.m0 = saved_rcu, o0P, h0P, m0
         ctx.generation = pack.generation
+        ctx.param_refs = params  # the Parameter objects themselves: their FlatAdamW gradient slots are looked up in backward
         ctx.save_for_backward(*params)
         return logits
 
@@ -129,8 +130,15 @@ class _DPTViT(torch.autograd.Function):
         M2 = B * H2 * W2
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
 
+        from .functional import _grad_dst
+
+        dst_of = {id(d): r for d, r in zip(det, getattr(ctx, "param_refs", det))}
+
         def new_like(p):
-            return torch.empty(p.shape, dtype=torch.float32, device=dev)
+            """Gradient buffer for parameter ``p``: its slot in FlatAdamW's flat gradient (autograd then adopts it: no copy, no
+            accumulate-add), else a fresh tensor."""
+            d = _grad_dst(dst_of.get(id(p)), tuple(p.shape))
+            return d if d is not None else torch.empty(p.shape, dtype=torch.float32, device=dev)
 
         def bias_grad(gF, N, n_true=None):
             db = torch.empty(N, dtype=torch.float32, device=dev)

@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmvp_hip.so")
+# MVP_LIB: diagnostic override (A/B builds of the same ABI, e.g. tools/tn_bench.py); the product default is the in-tree library
+LIB_PATH = os.environ.get("MVP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libmvp_hip.so")
 
 PREC_BF16 = 1
 PREC_BF16X3 = 3
