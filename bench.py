@@ -356,7 +356,10 @@ def main():
     if rank == 0:
         out = {
             "metric": "images/sec feature-extract+probe-step, ViT-B/16 224^2" if (H, W) == (224, 224) else f"images/sec feature-extract+probe-step, ViT-B/16 {H}x{W}",
-            "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0,
+            "value": round(images_per_s, 2), "unit": "images/s",
+            # a gloo run with MVP_FORCE_DEVICE is a control-flow rehearsal of several ranks on ONE card: it is not an N-GPU number
+            "n_gpus": 1 if (backend == "gloo" and os.environ.get("MVP_FORCE_DEVICE") is not None) else world,
+            "ranks": world, "rccl_ranks": world if backend == "nccl" else 0,
             "dist_backend": backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/LN/softmax/loss)" if args.precision == "bf16x3" else "bf16 (MFMA, fp32 accumulate)",

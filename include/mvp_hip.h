@@ -482,6 +482,18 @@ typedef struct {
 int mvp_maxpool_cl(const mvp_maxpool_cl_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * ResNet-50 stem fused: conv 7x7 / 2 / pad 3 (3 -> 64, BatchNorm folded into w / bias) + ReLU + max-pool 3x3 / 2 / pad 1,
+ * NCHW fp32 image -> channels-last [B, Hp, Wp, 64] (torchvision resnet50.conv1/bn1/relu/maxpool, dino_res50.py:38-44,83-90).
+ * w_hi/lo [64, 160] bf16: k = (ky*7 + kx)*3 + c, zero padded from 147.  Ho = (H-1)/2+1, Hp = (Ho-1)/2+1 (same for W).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* images; const mvp_bf16* w_hi; const mvp_bf16* w_lo; const float* bias;
+  float* out_f32; mvp_bf16* out_hi; mvp_bf16* out_lo;
+  int B, H, W, precision;
+} mvp_stem_args;
+int mvp_stem7x7_pool(const mvp_stem_args*, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Gradient gate + split: dst = src * (mask != 0) as fp32 (may alias src) and as a bf16 pair
  * with row stride ldo >= N (pad columns zeroed) — the ReLU backward of probes.py:283-288 fused
  * with the operand conversion for the next MFMA GEMM.  mask may be NULL (plain split).

@@ -333,11 +333,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   __syncthreads();  // every wave is done with the staging buffers -> reuse them for the epilogue
 
   if (KSPLIT && S > 1) {
-    // Cross-workgroup hand-over WITHOUT device-scope fences (a __threadfence() here writes back / invalidates the
-    // XCD's L2 once per workgroup: measured 3x slower GEMMs).  Every access to the shared bytes carries the scope
-    // itself: partials leave with 16-byte `sc1` (write-through) stores that the storing wave waits for (vmcnt(0))
-    // before the workgroup's ONE agent-scope atomic add; the workgroup whose add returned S-1 came last and reads
-    // all partials back with `sc1` loads after a workgroup barrier (MI355X_MICROARCH.md, hand-off table).
+    // Cross-workgroup hand-over without a per-workgroup release fence (a __threadfence() in every workgroup writes back /
+    // invalidates the XCD's L2 each time: measured 3x slower GEMMs).  Partials leave with 16-byte `sc1` (write-through) stores
+    // that the storing wave waits for (vmcnt(0)) before the barrier and the workgroup's ONE agent-scope atomic add; only the
+    // workgroup whose add returned S-1 (it came last) pays one agent-scope acquire, then reads all partials with `sc1` loads
+    // (MI355X_MICROARCH.md, "Valid forms" + hand-off table; stated in full at the acquire below).
     int* ctr = (int*)p.splitk_ws;
     constexpr int NACC = NT * MT;
     constexpr int UNIT_BYTES = NACC * NT_THREADS * 16;  // [acc register][thread] float4: 1-KiB wave accesses
@@ -357,6 +357,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
     if (tid == 0) s_last = (__hip_atomic_fetch_add(ctr + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
+    // Consumer side, MI355X_MICROARCH.md "Valid forms": ONE relaxed RMW told this workgroup it came last -> ONE agent-scope
+    // acquire (invalidates this CU's vector L1) -> vmcnt(0) -> workgroup barrier -> loads.  The measured sc1-only hand-off
+    // (no acquire) covers one workgroup per CU; several of these are resident per CU, so the acquire stays.  Producer side
+    // needs no agent release because every handed-off byte left with an sc1 (write-through) store that its wave waited for
+    // before the barrier that precedes the counter add (conditions (2) and (3) there).
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int sp = 0; sp < S; ++sp) {  // fixed order 0..S-1 whichever unit reduces -> bit-reproducible
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part + ((size_t)bid * S + sp) * UNIT_BYTES, 0, UNIT_BYTES, 0x00020000);
 #pragma unroll

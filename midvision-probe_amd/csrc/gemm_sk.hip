@@ -77,7 +77,7 @@ __device__ __forceinline__ void sk_tile(int L, int TM, int TN, int M, int N, int
 template <int SPLIT, bool SPEC>
 __global__ __launch_bounds__(SK_NW * 64) void gemm_sk_kernel(const mvp_gemm_args p, const int tiles, const int nk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = SK_BM, BN = SK_BN, BK = SK_BK, NW = SK_NW;
+  constexpr int BM = SK_BM, BN = SK_BN, BK = SK_BK;
   constexpr int CW = SPEC ? 4 : 8;                    // MFMA ("compute") waves
   constexpr int LW = SPEC ? 4 : 8;                    // waves that issue LDS-DMA
   constexpr int WNW = 2;
@@ -250,6 +250,10 @@ __global__ __launch_bounds__(SK_NW * 64) void gemm_sk_kernel(const mvp_gemm_args
       if (tid == 0) s_last = (__hip_atomic_fetch_add(ctr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
       __syncthreads();
       if (!s_last) continue;
+      // last arriver: one agent-scope acquire -> vmcnt(0) -> barrier -> sc1 loads (same protocol as gemm.hip's split-K)
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
       if (is_mma)
       for (int w = w_first; w <= w_last; ++w) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(part + ((size_t)w * 2 + (w == w_last ? 0 : 1)) * SK_PART_BYTES, 0, SK_PART_BYTES, 0x00020000);

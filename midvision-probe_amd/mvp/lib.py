@@ -167,6 +167,11 @@ class MaxpoolClArgs(C.Structure):
                 ("Ho", _i), ("Wo", _i), ("k", _i), ("stride", _i), ("pad", _i)]
 
 
+class StemArgs(C.Structure):
+    _fields_ = [("images", _vp), ("w_hi", _vp), ("w_lo", _vp), ("bias", _vp), ("out_f32", _vp), ("out_hi", _vp), ("out_lo", _vp),
+                ("B", _i), ("H", _i), ("W", _i), ("precision", _i)]
+
+
 class MaskSplitArgs(C.Structure):
     _fields_ = [("src", _vp), ("mask", _vp), ("dst_f32", _vp), ("dst_hi", _vp), ("dst_lo", _vp), ("M", _i64), ("N", _i),
                 ("lds", _i), ("ldm", _i), ("ldo", _i), ("relu_mask_out", _vp)]
@@ -222,6 +227,7 @@ SYMBOLS = {
     "mvp_linear_bins_bwd": LinearBinsArgs,
     "mvp_im2col_nchw": Im2colArgs,
     "mvp_maxpool_cl": MaxpoolClArgs,
+    "mvp_stem7x7_pool": StemArgs,
     "mvp_gemm_tn_workspace_bytes": None,
     "mvp_gemm_tn_conv": GemmTnArgs,
 }

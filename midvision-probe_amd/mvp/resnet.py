@@ -10,6 +10,7 @@ downsample = implicit-GEMM conv mode; 1x1 = plain GEMM; bottleneck tail = GEMM e
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -63,10 +64,19 @@ class ResNetEngine:
         self.stage_channels = [self.c0] + [st[-1]["cout"] for st in self.blocks]
 
     # ------------------------------------------------------------------ stages (x = (fp32, pair), H, W)
-    def _stem(self, images: torch.Tensor):
+    def _stem(self, images: torch.Tensor, want_f32: bool = False):
+        """conv1 7x7/2 + folded bn1 + ReLU + maxpool 3x3/2 in ONE kernel (csrc/stem.hip): image -> channels-last pooled map.
+        (MVP_STEM=im2col selects the older im2col + GEMM + pool form, kept for A/B measurements and as a cross-check.)"""
         B, Cin, H, W = images.shape
         pr, dev = self.pr, self.device
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        if Cin == 3 and self.c0 == 64 and os.environ.get("MVP_STEM", "fused") != "im2col":
+            Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+            pf = torch.empty(B * Hp * Wp, self.c0, dtype=torch.float32, device=dev) if want_f32 else None
+            pp = ops.empty_pair((B * Hp * Wp, self.c0), pr, dev)
+            lib.call("mvp_stem7x7_pool", lib.StemArgs(lib.ptr(images), lib.ptr(self.stem_w[0]), lib.ptr(self.stem_w[1]), lib.ptr(self.stem_b), lib.ptr(pf),
+                                                       lib.ptr(pp[0]), lib.ptr(pp[1]), B, H, W, pr))
+            return pf, pp, Hp, Wp
         col = ops.empty_pair((B * Ho * Wo, self.stem_k), pr, dev)
         lib.call("mvp_im2col_nchw", lib.Im2colArgs(lib.ptr(images), lib.ptr(col[0]), lib.ptr(col[1]), B, Cin, H, W, Ho, Wo, 7, 7, 2, 3, self.stem_k))
         y = torch.empty(B * Ho * Wo, self.c0, dtype=torch.float32, device=dev)
@@ -110,7 +120,7 @@ class ResNetEngine:
         B = images.shape[0]
         outs = TapOutputs()
         outs.tokens, outs.dims = [], []
-        xF, xP, H, W = self._stem(images)
+        xF, xP, H, W = self._stem(images, want_f32=0 in multilayers)
         last = max(multilayers)
         for i in range(5):
             if i > 0:

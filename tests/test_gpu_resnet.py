@@ -63,3 +63,52 @@ def test_mocov3_resnet50_single_layer_with_upsample(dev):
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-3
     raw = MoCoV3_RES(return_layers=[1, 2, 3, 4], add_norm=False, fixed_size=128, weights=sd).to(dev)(images.to(dev))
     assert rel_l2(raw.cpu().numpy(), ores.resnet_dense_features(sd, images, [4], fixed_size=128, add_norm=False).numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 96), (1, 61, 83), (3, 480, 480)])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_fused_stem_vs_torch(dev, shape, precision):
+    """csrc/stem.hip: conv 7x7/2 (folded BN) + ReLU + max-pool 3x3/2 in one kernel vs fp64 torch, odd sizes (ragged tiles, image
+    borders), and vs the older im2col + GEMM + pool form."""
+    import torch.nn.functional as F
+    from mvp import lib, ops
+    from mvp.vit import parse_precision
+
+    B, H, W = shape
+    pr = parse_precision(precision)
+    g = torch.Generator().manual_seed(H * W + B)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    b = torch.randn(64, generator=g) * 0.1
+    wk = torch.zeros(64, 160)
+    wk[:, :147] = w.permute(0, 2, 3, 1).reshape(64, -1)
+    wp = ops.split_bf16(wk.to(dev), pr)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    of = torch.full((B * Hp * Wp, 64), float("nan"), device=dev)
+    op = ops.empty_pair((B * Hp * Wp, 64), pr, dev)
+    lib.call("mvp_stem7x7_pool", lib.StemArgs(lib.ptr(x.to(dev)), lib.ptr(wp[0]), lib.ptr(wp[1]), lib.ptr(b.to(dev)), lib.ptr(of), lib.ptr(op[0]), lib.ptr(op[1]),
+                                               B, H, W, pr))
+    torch.cuda.synchronize()
+    xr, wr = (x, w) if pr == lib.PREC_BF16X3 else (x.bfloat16().float(), w.bfloat16().float())
+    ref = F.max_pool2d(F.relu(F.conv2d(xr.double(), wr.double(), b.double(), stride=2, padding=3)), 3, 2, 1)
+    assert tuple(ref.shape) == (B, 64, Hp, Wp)
+    got = of.view(B, Hp, Wp, 64).permute(0, 3, 1, 2).cpu()
+    tol = 2e-5 if pr == lib.PREC_BF16X3 else 1e-5
+    assert rel_l2(got.numpy(), ref.numpy()) < tol
+    pair = (op[0].float() + (op[1].float() if op[1] is not None else 0)).view(B, Hp, Wp, 64).permute(0, 3, 1, 2).cpu()
+    assert rel_l2(pair.numpy(), ref.numpy()) < (tol + 2e-5 if pr == lib.PREC_BF16X3 else 5e-3)
+
+
+def test_fused_stem_matches_im2col_path(dev, monkeypatch):
+    from mvp.resnet import ResNetEngine
+    from oracle import resnet as ores
+
+    sd = ores.make_resnet50_weights(seed=6)
+    eng = ResNetEngine(sd, device=dev)
+    images = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(3)).to(dev)
+    f1, p1, H1, W1 = eng._stem(images, want_f32=True)
+    monkeypatch.setenv("MVP_STEM", "im2col")
+    f2, p2, H2, W2 = eng._stem(images)
+    assert (H1, W1) == (H2, W2) == (32, 40)
+    assert rel_l2(f1.cpu().numpy(), f2.cpu().numpy()) < 1e-5
