@@ -78,3 +78,54 @@ def shard_pairs(n_pairs: int, rank: int, world: int):
     """Image pairs are independent (tap BN couples only the two images of a pair): rank r takes
     pairs r, r+W, ...; per-pair error vectors are gathered at the end."""
     return list(range(rank, n_pairs, world))
+
+
+def evaluate_dataset(model, dataset, thresh, verbose=False, rank: int = 0, world: int = 1):
+    """Reference: evaluate_spair_correspondence.py:104-121 -> (recall in %, confusion matrix).  With world > 1 the pairs are sharded
+    (rank r takes pairs r, r + W, ...; pairs are independent) and the per-pair error / index vectors are gathered with
+    one all_gather_object at the end (host-side lists of a few floats per pair), so every rank returns the full-dataset result."""
+    idx = shard_pairs(len(dataset), rank, world)
+    outs = [(i,) + tuple(t.cpu() for t in compute_errors(model, dataset[i])) for i in idx]
+    if world > 1:
+        import torch.distributed as dist
+
+        gathered = [None] * world
+        dist.all_gather_object(gathered, outs)
+        outs = sorted((o for part in gathered for o in part), key=lambda o: o[0])  # dataset order, as the reference's single loop
+    errors = torch.cat([o[1] for o in outs])
+    src_ind = torch.cat([o[3] for o in outs])
+    tgt_ind = torch.cat([o[4] for o in outs])
+    kp_max = int(max(src_ind.max(), tgt_ind.max())) + 1
+    confusion = torch.zeros((kp_max, kp_max))
+    for src, tgt in torch.stack((src_ind, tgt_ind), dim=1):
+        confusion[src, tgt] += 1
+    recall = (errors < thresh).float().mean().item() * 100.0
+    return recall, confusion
+
+
+class SyntheticSPair(torch.utils.data.Dataset):
+    """SPair-71k-shaped instances (evals/datasets/spair.py contract consumed by compute_errors): (img_i, mask_i, kps_i [K,3],
+    img_j, mask_j, kps_j [K,3], thresh_scale, meta).  img_j is img_i shifted by a whole number of patches, so that a feature
+    extractor with any spatial sensitivity can solve it: used by the tests and the config-#5 entry script (no dataset files in scope)."""
+
+    def __init__(self, num_pairs=8, image_size=800, num_kps=20, seed=0, patch=16):
+        self.n, self.S, self.K, self.seed, self.patch = num_pairs, image_size, num_kps, seed, patch
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        import numpy as np
+
+        g = torch.Generator().manual_seed(self.seed * 7919 + i)
+        S, P = self.S, self.patch
+        img_i = torch.randn(3, S, S, generator=g)
+        dy, dx = (int(v) for v in torch.randint(-2, 3, (2,), generator=g))
+        img_j = torch.roll(img_i, shifts=(dy * P, dx * P), dims=(1, 2))
+        margin = 3 * P
+        kp = torch.randint(margin, S - margin, (self.K, 2), generator=g).float()  # (x, y)
+        vis = (torch.rand(self.K, 1, generator=g) > 0.1).float()
+        kps_i = torch.cat([kp, vis], 1)
+        kps_j = torch.cat([kp + torch.tensor([dx * P, dy * P], dtype=torch.float32), vis], 1)
+        mask = np.ones((S, S))
+        return img_i, mask, kps_i, img_j, mask, kps_j, 1.0, {"pair": i}

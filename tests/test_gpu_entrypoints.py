@@ -1,0 +1,64 @@
+"""The entry scripts end to end on the GPU (compose config -> instantiate -> train -> validate (SA + SI) -> result CSV -> ckpt.pth),
+as a user of the reference would run them: `python train_depth.py backbone=... probe=...` (train_depth.py:542-855),
+`train_snorm.py`, `evaluate_spair_correspondence.py`; plus the self-launch of `system.num_gpus=2` (two ranks share cuda:0 over gloo)."""
+import csv
+import glob
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "midvision-probe_amd")
+
+
+def _run(script, args, cwd, extra_env=None, timeout=600):
+    env = dict(os.environ, **(extra_env or {}))
+    p = subprocess.run([sys.executable, os.path.join(PKG, script)] + args, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    out = p.stdout.decode(errors="replace")
+    assert p.returncode == 0, out[-4000:]
+    return out
+
+
+COMMON = ["dataset.image_size=[64,96]", "dataset.num_batches=3", "batch_size=2", "optimizer=one_epoch", "num_workers=0"]
+
+
+@pytest.mark.timeout(900)
+def test_train_depth_entrypoint_writes_csv_and_checkpoint(tmp_path):
+    out = _run("train_depth.py", ["backbone=dino_b16", "+backbone.return_multilayer=True", "probe=depth_linear", f"output_dir={tmp_path}/result"] + COMMON, str(tmp_path))
+    assert "SA valid loss" in out and "results ->" in out and "saved" in out
+    files = glob.glob(str(tmp_path / "result" / "result" / "depth" / "depth_results_synthetic_final_with_batchnorm.csv"))
+    assert len(files) == 1
+    rows = list(csv.reader(open(files[0])))
+    assert len(rows) == 2 and len(rows[0]) == len(rows[1])
+    titles = rows[0]
+    assert titles[:2] == ["Timestamp", "Model Checkpoint"] and "rmse SA" in titles and "rmse SI" in titles and "Level level_5 rmse SI" in titles
+    assert "stuff_d1 SA" in titles and titles[-1] == "ckpt_path"
+    ck = rows[1][-1]
+    assert os.path.isfile(ck)
+    blob = torch.load(ck, map_location="cpu", weights_only=True)
+    assert set(blob) == {"cfg", "model", "probe"} and set(blob["probe"]) == {"head.conv.weight", "head.conv.bias"}
+    assert float(rows[1][titles.index("rmse SA")]) > 0
+
+
+@pytest.mark.timeout(900)
+def test_train_snorm_and_spair_entrypoints(tmp_path):
+    out = _run("train_snorm.py", ["backbone=dino_b16", "+backbone.return_multilayer=True", "probe=snorm_dpt", "probe.hidden_dim=128", f"output_dir={tmp_path}/result"] + COMMON, str(tmp_path))
+    assert "valid d1" in out and "saved" in out
+    out = _run("evaluate_spair_correspondence.py", ["backbone=ibot_b16", "image_size=160", "num_instances=3"], str(tmp_path))
+    assert "Recall@0.10" in out
+
+
+@pytest.mark.timeout(900)
+def test_train_depth_self_launches_two_ranks(tmp_path):
+    """system.num_gpus=2 without a torchrun environment: the script starts its own two ranks (train_depth.py:851-855 does mp.spawn);
+    on this one-GPU box they share cuda:0 over gloo.  Rank 0 validates and writes the row; global batch in the row = 2 x 2."""
+    out = _run("train_depth.py", ["backbone=dino_b16", "+backbone.return_multilayer=True", "probe=depth_linear", "system.num_gpus=2", f"output_dir={tmp_path}/result"] + COMMON,
+               str(tmp_path), extra_env={"MVP_DIST_BACKEND": "gloo", "MVP_FORCE_DEVICE": "0", "OMP_NUM_THREADS": "2"})
+    assert "results ->" in out
+    rows = list(csv.reader(open(glob.glob(str(tmp_path / "result" / "result" / "depth" / "*.csv"))[0])))
+    assert rows[1][rows[0].index("Batch Size")].strip() == "4"

@@ -286,3 +286,19 @@ def test_dino_output_types_vs_oracle(dev, output, add_norm):
     for o, r in zip(outs, ref):
         assert o.shape == r.shape and (o.shape == (3, C2, 6, 8) if output == "dense-cls" else o.shape == (3, 768))
         assert rel_l2(o.cpu().numpy(), r.numpy()) < 1e-3
+
+
+def test_spair_evaluate_dataset(dev):
+    """evaluate_dataset (evaluate_spair_correspondence.py:104-121) over synthetic pairs: recall / confusion equal a plain loop over
+    compute_errors, and pair sharding (rank r takes r, r+W, ...) partitions the dataset."""
+    from evals.models.ibot import iBOT
+    from mvp import spair
+
+    sd = _weights(56)
+    model = iBOT(add_norm=True, weights=sd).to(dev)
+    ds = spair.SyntheticSPair(num_pairs=5, image_size=160, num_kps=9, seed=3)
+    recall, conf = spair.evaluate_dataset(model, ds, 0.10)
+    errs = torch.cat([spair.compute_errors(model, ds[i])[0] for i in range(len(ds))])
+    assert abs(recall - (errs < 0.10).float().mean().item() * 100.0) < 1e-9
+    assert conf.sum().item() == errs.numel() and 0.0 <= recall <= 100.0
+    assert sorted(spair.shard_pairs(5, 0, 2) + spair.shard_pairs(5, 1, 2)) == [0, 1, 2, 3, 4]
