@@ -13,9 +13,10 @@ OUT = os.path.join(REPO, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
 
 
-def build(ablate, extra=""):
-    so = os.path.join(OUT, f"libattn_ab{ablate}.so")
-    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ATT_ABLATE={ablate} {extra} {CS}/attention.hip -o {so}"
+def build(ablate, extra="", src=None, tag=""):
+    so = os.path.join(OUT, f"libattn_ab{ablate}{tag}.so")
+    src = src or f"{CS}/attention.hip"
+    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ATT_ABLATE={ablate} {extra} {src} -o {so}"
     subprocess.run(cmd, shell=True, check=True)
     l = C.CDLL(so)
     l.mvp_attention_fwd.argtypes = [C.POINTER(lib.AttentionArgs), C.c_void_p]
@@ -26,9 +27,12 @@ def build(ablate, extra=""):
 def main():
     names = {0: "full", 1: "no_softmax", 2: "no_pv", 3: "no_s", 4: "no_stage", 5: "no_tiles"}
     variants = {names[a]: build(a) for a in names}
+    prev = os.path.join(REPO, "tools", "micro", "attention_prev.hip")
+    if "--ab" in sys.argv and os.path.exists(prev):  # A/B against a saved earlier version of the kernel
+        variants = {"full": build(0), "prev": build(0, src=prev, tag="_prev")}
     dev = torch.device("cuda")
     B = int(os.environ.get("B", 16)); H = 12
-    for N in (197, 785):
+    for N in (197, 785, 1201):
         for prec in (3, 1):
             qkv = ops.split_bf16(torch.randn(B * N, 3 * H * 64, device=dev), 3)
             out = ops.empty_pair((B * N, H * 64), 3, dev)
