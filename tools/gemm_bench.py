@@ -11,9 +11,10 @@ CS = os.path.join(REPO, "midvision-probe_amd", "csrc")
 OUT = os.path.join(REPO, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
 
-def build(ablate, extra=""):
-    so = os.path.join(OUT, f"libgemm_ab{ablate}{extra.replace(' ','').replace('-D','_').replace('=','')}.so")
-    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ABLATE={ablate} {extra} {CS}/gemm.hip {CS}/gemm_sk.hip -o {so}"
+def build(ablate, extra="", src=None, tag=""):
+    so = os.path.join(OUT, f"libgemm_ab{ablate}{extra.replace(' ','').replace('-D','_').replace('=','')}{tag}.so")
+    src = src or f"{CS}/gemm.hip"
+    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ABLATE={ablate} {extra} {src} {CS}/gemm_sk.hip -o {so}"
     subprocess.run(cmd, shell=True, check=True)
     l = C.CDLL(so)
     l.mvp_gemm_bias_act_res.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
@@ -30,6 +31,9 @@ def main():
                 variants["%dx%dk%ds%dw%dn%d" % c] = cfg(*c)
             except Exception as e:
                 print("build failed", c)
+    prev = os.path.join(REPO, "tools", "micro", "gemm_prev.hip")
+    if "--ab" in sys.argv and os.path.exists(prev):  # A/B against a saved earlier version of gemm.hip
+        variants = {"auto": variants["auto"], "prev": build(0, src=prev, tag="_prev")}
     if "--sk" in sys.argv:
         variants = {"auto": variants["auto"], "streamk_spec": build(0, "-DMVP_SK_SPEC=1"), "streamk_il": build(0, "-DMVP_SK_SPEC=0 -DMVP_SK_DMA_INTERLEAVE=1"),
                     "streamk_burst": build(0, "-DMVP_SK_SPEC=0 -DMVP_SK_DMA_INTERLEAVE=0")}

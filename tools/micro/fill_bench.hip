@@ -15,6 +15,10 @@
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 typedef __attribute__((ext_vector_type(4))) float f4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+#ifndef NMFMA
+#define NMFMA 0   // MFMAs issued by the same wave after every LDS-DMA piece (variant 6)
+#endif
 
 template <int V, int ROWS, int DEPTH>
 __global__ __launch_bounds__(256) void fill(const char* __restrict__ src, size_t foot, int ld, int nk, float* sink) {
@@ -23,6 +27,9 @@ __global__ __launch_bounds__(256) void fill(const char* __restrict__ src, size_t
   constexpr int PIECES = ROWS * 2 / 8 / 4;  // 1-KiB pieces per wave per k-tile (hi + lo arrays)
   const size_t half = foot / 2;
   f4 acc = {0, 0, 0, 0};
+  f4 macc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  bf8 ma, mb;
+  for (int e = 0; e < 8; ++e) { ma[e] = (__bf16)(0.001f * (lane + e)); mb[e] = (__bf16)(0.002f * (lane - e)); }
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)foot, 0x00020000);
   // every workgroup starts at its own offset and walks forward
   size_t base = ((size_t)blockIdx.x * 7919u * 1024u) % (half / 2);
@@ -32,7 +39,7 @@ __global__ __launch_bounds__(256) void fill(const char* __restrict__ src, size_t
     for (int ps = 0; ps < PIECES; ++ps) {
       const int arr = ps & 1, piece = (ps >> 1) * 4 + wave;   // piece index inside the array's tile
       size_t off;
-      if (V == 0 || V == 2 || V == 3 || V == 5) {   // strided rows: piece = 8 rows x 128 B
+      if (V == 0 || V == 2 || V == 3 || V == 5 || V == 6 || V == 7) {   // strided rows: piece = 8 rows x 128 B
         const int row = piece * 8 + (lane >> 3);
         off = ((size_t)row * ld + (size_t)kt * 128 + (lane & 7) * 16);
       } else {                            // contiguous: tile kt of this workgroup is one block
@@ -43,6 +50,14 @@ __global__ __launch_bounds__(256) void fill(const char* __restrict__ src, size_t
       const char* g = src + arr * half + off;
       if (V == 0 || V == 1) {
         __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(buf + arr * ROWS * 128 + piece * 1024), 16, 0, 0);
+      } else if (V == 6) {  // the GEMM situation: operand fill and MFMAs from the same SIMD
+        __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(buf + arr * ROWS * 128 + piece * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NMFMA; ++q) macc[q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, mb, macc[q & 3], 0, 0, 0);
+      } else if (V == 7) {  // buffer form + MFMAs
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(buf + arr * ROWS * 128 + piece * 1024), 16, (int)(arr * half + off), 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NMFMA; ++q) macc[q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ma, mb, macc[q & 3], 0, 0, 0);
       } else if (V == 5) {  // buffer form: SGPR resource + 32-bit per-lane offset
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(buf + arr * ROWS * 128 + piece * 1024), 16, (int)(arr * half + off), 0, 0, 0);
       } else {
@@ -64,6 +79,7 @@ __global__ __launch_bounds__(256) void fill(const char* __restrict__ src, size_t
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  acc += macc[0] + macc[1] + macc[2] + macc[3];
   if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[0] = acc[0];
 }
 
@@ -99,6 +115,8 @@ int main(int argc, char** argv) {
     run<0, 128, 1>("V0 lds-dma strided  (single)", src, foot, sink, grid, nk, p + 128 * 128 * 2);
     run<0, 128, 2>("V0 lds-dma strided  (2-stage)", src, foot, sink, grid, nk, p);
     run<5, 128, 2>("V5 buffer_load-lds strided (2-stage)", src, foot, sink, grid, nk, p);
+    run<6, 128, 2>("V6 lds-dma strided + NMFMA mfma/piece", src, foot, sink, grid, nk, p);
+    run<7, 128, 2>("V7 buffer-lds strided + NMFMA mfma/piece", src, foot, sink, grid, nk, p);
     run<1, 128, 2>("V1 lds-dma contiguous (2-stage)", src, foot, sink, grid, nk, p);
     run<2, 128, 2>("V2 regs strided", src, foot, sink, grid, nk, p);
     run<4, 128, 2>("V4 regs contiguous", src, foot, sink, grid, nk, p);

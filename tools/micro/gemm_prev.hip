@@ -39,15 +39,6 @@
 
 namespace {
 
-// One LDS-DMA piece in the buffer form (buffer_load_dwordx4 ... lds): SGPR resource {base, num_records = bytes}, 32-bit per-lane
-// byte offset, wave-uniform byte offset in an SGPR.  Offsets at or beyond `bytes` read zeros.  (A __device__-only helper: with
-// the builtin written directly inside the kernel template's staging lambda the HOST pass of ROCm 7.2's clang silently drops
-// every instantiation of the kernel — no diagnostic, undefined __device_stub__ symbols at link time.)
-__device__ __forceinline__ void lds_dma16(const void* base, unsigned bytes, char* lds_dst, int voff, int soff) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
-}
-
 // split-K workspace = [tile counters: fixed 64 KiB region][fp32 partial tiles]; the fixed counter region keeps the
 // counters of GEMMs of different shapes that share one workspace apart from each other's partials.
 constexpr int SPLITK_CTR_BYTES = 65536;
@@ -165,49 +156,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   }
   const int cHs = CONV ? (p.cH >> p.cup) : 0, cWs = CONV ? (p.cW >> p.cup) : 0;
 
-  // Operand staging = LDS-DMA in the BUFFER form (buffer_load_dwordx4 ... lds): an SGPR resource per operand array, a 32-bit
-  // per-lane byte offset that is computed ONCE (row * ld + swizzled chunk) and the k offset of the tile in an SGPR.  Against
-  // global_load_lds with 64-bit per-lane addresses this removes the per-tile address arithmetic and costs the issuing SIMD less
-  // (tools/micro/fill_bench.hip: +5...9 % fill rate with MFMAs issued beside it); out-of-range offsets return zeros, which is how
-  // the convolution's padding taps are read (no zero page, no pointer select).  Resources are rebased to the tile's first row
-  // (linear) so that offsets stay far below 2^31 for any M.
-  const size_t a_base = CONV ? 0 : (size_t)m0 * p.lda;
-  const unsigned a_bytes = CONV ? (unsigned)min((size_t)0x7fffff00u, ((size_t)(p.M / (p.cHo * p.cWo)) * cHs * cWs * p.lda) * 2) : 0x7fffff00u;
-  // (the resource descriptors are rebuilt from these base pointers inside the lambda: a lambda capturing a variable of the opaque
-  // __amdgpu_buffer_rsrc_t type makes the HOST pass drop the whole kernel template without a diagnostic — ROCm 7.2 clang)
-  mvp_bf16* const pa_hi = (mvp_bf16*)p.a_hi + a_base;
-  mvp_bf16* const pa_lo = (mvp_bf16*)(SPLIT == 3 ? p.a_lo : p.a_hi) + a_base;
-  const size_t w_base = (size_t)n0 * p.ldw;
-  mvp_bf16* const pw_hi = (mvp_bf16*)p.w_hi + w_base;
-  mvp_bf16* const pw_lo = (mvp_bf16*)(SPLIT == 3 ? p.w_lo : p.w_hi) + w_base;
-  int a_voff[APASS], w_voff[BN / (NW * RPP)];
-#pragma unroll
-  for (int ps = 0; ps < APASS; ++ps) {
-    const int grow = min(ps * NW * RPP + wave * RPP + rsub, p.M - 1 - m0);  // rows past M re-read the last row (never stored)
-    a_voff[ps] = CONV ? 0 : (grow * p.lda + csrc) * 2;
-  }
-#pragma unroll
-  for (int ps = 0; ps < BN / (NW * RPP); ++ps) {
-    const int grow = min(ps * NW * RPP + wave * RPP + rsub, p.N - 1 - n0);
-    w_voff[ps] = (grow * p.ldw + csrc) * 2;
-  }
-
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * STAGE;
-    const int k0b = (kt0 + kt) * BK * 2;  // byte offset of the k-tile inside a row: wave-uniform (SGPR)
+    const int k0 = (kt0 + kt) * BK;
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps) {
       const int r = ps * NW * RPP + wave * RPP;
       if (CONV) {
         const int yy = cvy[ps] + ct_ky, xx = cvx[ps] + ct_kx;
         const bool ok = ((unsigned)yy < (unsigned)p.cH) && ((unsigned)xx < (unsigned)p.cW);
-        const int off = ((((cvb[ps] * cHs + (yy >> p.cup)) * cWs + (xx >> p.cup)) * p.lda) + ct_c0 + csrc) * 2;
-        const int voff = ok ? off : 0x7fffff80;  // padding tap: beyond num_records -> the load returns zeros
-        lds_dma16(pa_hi, a_bytes, base + r * ROWB, voff, 0);
-        if (SPLIT == 3) lds_dma16(pa_lo, a_bytes, base + A_BYTES + r * ROWB, voff, 0);
+        const size_t off = (((size_t)cvb[ps] * cHs + (yy >> p.cup)) * cWs + (xx >> p.cup)) * p.lda + ct_c0 + csrc;
+        const mvp_bf16* sh = ok ? p.a_hi + off : p.zero_page + csrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(sh), LDS_PTR(base + r * ROWB), 16, 0, 0);
+        if (SPLIT == 3) {
+          const mvp_bf16* sl = ok ? p.a_lo + off : p.zero_page + csrc;
+          __builtin_amdgcn_global_load_lds(GLB_PTR(sl), LDS_PTR(base + A_BYTES + r * ROWB), 16, 0, 0);
+        }
       } else {
-        lds_dma16(pa_hi, a_bytes, base + r * ROWB, a_voff[ps], k0b);
-        if (SPLIT == 3) lds_dma16(pa_lo, a_bytes, base + A_BYTES + r * ROWB, a_voff[ps], k0b);
+        const int grow = min(m0 + r + rsub, p.M - 1);
+        const size_t off = (size_t)grow * p.lda + k0 + csrc;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_hi + off), LDS_PTR(base + r * ROWB), 16, 0, 0);
+        if (SPLIT == 3)
+          __builtin_amdgcn_global_load_lds(GLB_PTR(p.a_lo + off), LDS_PTR(base + A_BYTES + r * ROWB), 16, 0, 0);
       }
     }
     if (CONV) {  // tiles are staged in increasing kt order: advance the running tap position
@@ -221,8 +191,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
 #pragma unroll
     for (int ps = 0; ps < BN / (NW * RPP); ++ps) {
       const int r = ps * NW * RPP + wave * RPP;
-      lds_dma16(pw_hi, 0x7fffff00u, wb + r * ROWB, w_voff[ps], k0b);
-      if (SPLIT == 3) lds_dma16(pw_lo, 0x7fffff00u, wb + W_BYTES + r * ROWB, w_voff[ps], k0b);
+      const int grow = min(n0 + r + rsub, p.N - 1);
+      const size_t off = (size_t)grow * p.ldw + k0 + csrc;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_hi + off), LDS_PTR(wb + r * ROWB), 16, 0, 0);
+      if (SPLIT == 3)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p.w_lo + off), LDS_PTR(wb + W_BYTES + r * ROWB), 16, 0, 0);
     }
   };
 
@@ -629,8 +602,6 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     if (!a->zero_page || a->cC <= 0 || (a->cC & 31) || a->ckh <= 0 || a->ckw <= 0 || a->cstride <= 0) return MVP_EINVAL;
     if (a->K != a->ckh * a->ckw * a->cC || a->cHo <= 0 || a->cWo <= 0 || (a->M % (a->cHo * a->cWo))) return MVP_EINVAL;
     if ((a->cH & ((1 << a->cup) - 1)) || (a->cW & ((1 << a->cup) - 1))) return MVP_EINVAL;
-    // the buffer-form staging addresses the activation with 32-bit byte offsets (out-of-range = padding): it must stay below 2 GiB
-    if ((int64_t)(a->M / (a->cHo * a->cWo)) * (a->cH >> a->cup) * (a->cW >> a->cup) * a->lda * 2 >= 0x7fffff00ll) return MVP_EINVAL;
     // A K-tile must stay inside one tap: BK = 64 (whole-line rows, single stage: see the tile notes below) when
     // C % 64 == 0, else BK = 32 (any C % 32 == 0), two stages.
     if (x3 && (a->cC & 63) == 0) {
