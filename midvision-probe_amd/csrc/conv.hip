@@ -197,32 +197,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_conv_kernel(const mvp_gemm_tn
       const int64_t m = mbeg + (int64_t)kt * KT + r;
       const int cs = (c16 ^ (fsw(r) << 1)) << 3;   // swizzled source chunk (elements)
       const bool inr = m < mend;
-      // G row
-      const size_t goff = (size_t)(inr ? m : 0) * p.ldg + i0 + cs;
-      const mvp_bf16* gh = inr ? p.g_hi + goff : p.zero_page + cs;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(gh), LDS_PTR(base + (wave * RPW + ps * 4) * 256), 16, 0, 0);
-      if (SPLIT == 3) {
-        const mvp_bf16* gl = inr ? p.g_lo + goff : p.zero_page + cs;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(gl), LDS_PTR(base + TILE + (wave * RPW + ps * 4) * 256), 16, 0, 0);
-      }
+      // G row (buffer-form LDS-DMA: rows past the split's range and padding taps use an out-of-range offset -> zeros)
+      constexpr int OOB = 0x7fffff80;
+      constexpr unsigned NREC = 0x7fffff00u;
+      const int goff = inr ? (int)((m * p.ldg + i0 + cs) * 2) : OOB;
+      lds_dma16(p.g_hi, NREC, base + (wave * RPW + ps * 4) * 256, goff, 0);
+      if (SPLIT == 3) lds_dma16(p.g_lo, NREC, base + TILE + (wave * RPW + ps * 4) * 256, goff, 0);
       // X row of the tap's source pixel
-      bool ok = inr;
-      size_t xoff = 0;
+      int xoff = OOB;
       if (inr) {
         const int x = (int)(m % p.Wo);
         const int64_t t2 = m / p.Wo;
         const int y = (int)(t2 % p.Ho);
         const int64_t b = t2 / p.Ho;
         const int yy = y * p.stride + ky - p.pad, xx = x * p.stride + kx - p.pad;
-        ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W);
-        xoff = ((size_t)(b * Hs + (yy >> p.up)) * Ws + (xx >> p.up)) * p.ldx + c0 + cs;
+        if (((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W))
+          xoff = (int)((((b * Hs + (yy >> p.up)) * Ws + (xx >> p.up)) * p.ldx + c0 + cs) * 2);
       }
-      const mvp_bf16* xh = ok ? p.x_hi + xoff : p.zero_page + cs;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(xh), LDS_PTR(base + NARR * TILE + (wave * RPW + ps * 4) * 256), 16, 0, 0);
-      if (SPLIT == 3) {
-        const mvp_bf16* xl = ok ? p.x_lo + xoff : p.zero_page + cs;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(xl), LDS_PTR(base + 3 * TILE + (wave * RPW + ps * 4) * 256), 16, 0, 0);
-      }
+      lds_dma16(p.x_hi, NREC, base + NARR * TILE + (wave * RPW + ps * 4) * 256, xoff, 0);
+      if (SPLIT == 3) lds_dma16(p.x_lo, NREC, base + 3 * TILE + (wave * RPW + ps * 4) * 256, xoff, 0);
     }
   };
 
@@ -401,6 +394,8 @@ extern "C" int mvp_gemm_tn_conv(const mvp_gemm_tn_args* a, void* stream) {
   if (a->Cout <= 0 || a->Cin <= 0 || (a->Cin & 127) || a->M <= 0 || a->splits < 1) return MVP_EINVAL;
   if (a->kh <= 0 || a->kw <= 0 || a->stride <= 0 || a->Ho <= 0 || a->Wo <= 0 || (a->M % ((int64_t)a->Ho * a->Wo))) return MVP_EINVAL;
   if ((a->ldg & 7) || (a->ldx & 7) || a->ldx < a->Cin || a->ldg < ((a->Cout + 127) / 128) * 128) return MVP_EINVAL;
+  // 32-bit byte offsets in the buffer-form staging: both operand arrays must stay below 2 GiB
+  if (a->M * a->ldg * 2 >= 0x7fffff00ll || (a->M / ((int64_t)a->Ho * a->Wo)) * (a->H >> a->up) * (a->W >> a->up) * a->ldx * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   if (a->precision == MVP_PREC_BF16X3) {
     if (!a->g_lo || !a->x_lo) return MVP_EINVAL;
     // one LDS stage (+1.3 % over two on the DPT step) and 8 waves on the 128x128 tile (+5 %: 618 -> 649 img/s);

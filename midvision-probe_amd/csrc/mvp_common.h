@@ -62,6 +62,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// One LDS-DMA piece in the buffer form (buffer_load_dwordx4 ... lds): SGPR resource {base, num_records = bytes}, 32-bit per-lane
+// byte offset, wave-uniform byte offset in an SGPR.  Offsets at or beyond `bytes` read zeros.  (A __device__-only helper: with
+// the builtin written directly inside the kernel template's staging lambda the HOST pass of ROCm 7.2's clang silently drops
+// every instantiation of the kernel — no diagnostic, undefined __device_stub__ symbols at link time.)
+__device__ __forceinline__ void lds_dma16(const void* base, unsigned bytes, char* lds_dst, int voff, int soff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds_dst), 16, voff, soff, 0, 0);
+}
+
 #define MVP_LAUNCH_CHECK()                                   \
   do {                                                       \
     hipError_t e__ = hipGetLastError();                      \
