@@ -68,7 +68,7 @@ def test_config2_dino_vitb16_linear_bindepth_480x640_whole_step(dev):
     opt = FlatAdamW([{"params": probe.parameters(), "lr": ref.lr_at(0)}])
     loss = train_depth_step(model, probe, opt, None, DepthLoss(), images.to(dev), tgt.to(dev))
     assert abs(loss.item() - loss_ref.item()) < 2e-4 * abs(loss_ref.item())
-    _grad_check(probe, ref.probe_sd, rel=1e-2, cos=1e-4)
+    _grad_check(probe, ref.probe_sd, rel=5e-3, cos=1e-5)   # measured 1.7e-3 / 1.4e-6
     w, w_ref = probe.head.conv.weight.detach().cpu().numpy(), ref.probe_sd["head.conv.weight"].detach().numpy()
     assert rel_l2(w, w_ref) < 2e-3  # first Adam step = -lr*sign(g): near-zero gradients may flip sign (see test_snorm_train_step_vs_oracle)
 
@@ -109,7 +109,7 @@ def test_config3_mocov3_resnet50_dpt_snorm_step(dev):
     loss = train_snorm_step(model, probe, opt, None, images.to(dev), normals.to(dev), mask.to(dev))
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
-    _grad_check(probe, p_ref, rel=8e-2, cos=5e-3)
+    _grad_check(probe, p_ref, rel=6e-2, cos=2e-3)   # measured 3.0e-2 / 4.5e-4: ReLU-gate flips through 4 fusion stages
 
 
 # ---------------------------------------------------------------------------------------------------------------- config #4
@@ -154,7 +154,7 @@ def test_config4_mae_vitb16_dpt_bindepth_step(dev):
     loss = train_depth_step(model, probe, opt, None, DepthLoss(), images.to(dev), tgt.to(dev))
     torch.cuda.synchronize()
     assert abs(loss.item() - loss_ref.item()) < 5e-4 * abs(loss_ref.item())
-    _grad_check(probe, p_ref, rel=8e-2, cos=5e-3)
+    _grad_check(probe, p_ref, rel=3e-2, cos=5e-4)   # measured 9.7e-3 / 4.7e-5
 
 
 # ------------------------------------------------------------------------------------------------ ResNet trunk, large-M conv tiles
