@@ -68,6 +68,40 @@ def test_gemm_epilogues(dev, precision, shape):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def test_gemm_strided_operands_and_output_slices(dev, precision):
+    """Operands that are column slices of wider buffers (lda / ldw > K, non-zero column offset: how the DPT head reads one tap of the
+    packed features) and outputs written into column slices (ldo / ldob > N), ragged M and N: the buffer-form staging computes
+    per-lane offsets from lda / ldw once per workgroup and must honour all of them."""
+    from mvp import lib, ops
+    from mvp.vit import parse_precision
+
+    pr = parse_precision(precision)
+    g = torch.Generator().manual_seed(77)
+    for (M, N, K, LDA, LDW, LDO, aoff, woff, ooff) in ((1000, 200, 128, 512, 320, 264, 128, 64, 8), (77, 512, 256, 256, 1024, 512, 0, 256, 0), (3136, 128, 768, 3072, 768, 512, 1536, 0, 128)):
+        abuf, wbuf = torch.randn(M, LDA, generator=g), torch.randn(N, LDW, generator=g) * 0.05
+        bias = torch.randn(N, generator=g)
+        ap_full, wp_full = ops.split_bf16(abuf.to(dev), pr), ops.split_bf16(wbuf.to(dev), pr)
+        ap = (ap_full[0][:, aoff:], ap_full[1][:, aoff:] if ap_full[1] is not None else None)
+        wp = (wp_full[0][:, woff:], wp_full[1][:, woff:] if wp_full[1] is not None else None)
+        a, w = abuf[:, aoff:aoff + K], wbuf[:, woff:woff + K]
+        if pr == lib.PREC_BF16:
+            a, w = _bf16_round(a), _bf16_round(w)
+        ref = (a.double() @ w.double().t() + bias.double()).relu()
+        out = torch.full((M, LDO), float("nan"), device=dev)
+        oph = torch.zeros(M, LDO, dtype=torch.bfloat16, device=dev)
+        opl = torch.zeros(M, LDO, dtype=torch.bfloat16, device=dev)
+        ops.gemm(ap, wp, M, N, K, bias=bias.to(dev), out_f32=out[:, ooff:], out=(oph[:, ooff:], opl[:, ooff:]), act=lib.ACT_RELU, precision=pr,
+                 lda=LDA, ldw=LDW, ldo=LDO, ldob=LDO, splitk=1)
+        torch.cuda.synchronize()
+        got = out[:, ooff:ooff + N].cpu()
+        assert rel_l2(got.numpy(), ref.numpy()) < (2e-5 if pr == lib.PREC_BF16 else 5e-5), (M, N, K)
+        assert torch.isnan(out[:, :ooff]).all() and torch.isnan(out[:, ooff + N:]).all()  # nothing written outside the slice
+        pair = (oph.float() + opl.float())[:, ooff:ooff + N].cpu()
+        assert rel_l2(pair.numpy(), ref.numpy()) < 7e-5
+        assert (oph[:, :ooff] == 0).all() and (oph[:, ooff + N:] == 0).all()
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
 def test_gemm_splitk(dev, precision):
     """Split-K (last-arriving workgroup reduces in a fixed order): parity with fp64 for several split factors and
     both tile widths, bit-reproducible across launches, and shapes alternating on ONE workspace (the tile
