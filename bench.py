@@ -67,6 +67,52 @@ def pmc_mfma_busy(kernel: str):
     return None
 
 
+def live_pmc(extra_args):
+    """Memory-side traffic and MFMA-busy cycles of THIS invocation's workload, measured now: the parent — before it touches the GPU —
+    runs `rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py <same workload flags> --pmc-child` twice (FETCH_SIZE alone:
+    it takes 3 of the 4 TCC slots; then WRITE_SIZE + SQ_VALU_MFMA_BUSY_CYCLES), the way MI355X_MICROARCH.md prescribes (separate
+    passes, --kernel-trace only).  Returns {kernel name: {"hbm_bytes", "mfma_busy"}} averaged per launch, or None (no rocprofv3 /
+    a failed pass): bench.py then falls back to the newest committed profiles/rNN_pmc_* and says so."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None
+    me = os.path.abspath(__file__)
+    acc = {}
+    try:
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"]):
+            d = tempfile.mkdtemp(prefix="mvp_pmc_")
+            cmd = [rp, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, me, *extra_args, "--pmc-child"]
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()))
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            for path in files:
+                for row in csv.DictReader(open(path)):
+                    name = re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"])
+                    name = re.sub(r"^void ", "", name)
+                    name = re.sub(r"\(mvp_\w+( const\*)?(, [^)]*)?\)$", "", name)
+                    e = acc.setdefault(name, {})
+                    c = e.setdefault(row["Counter_Name"], [0.0, 0])
+                    c[0] += float(row["Counter_Value"])
+                    c[1] += 1
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception:
+        return None
+    out = {}
+    for name, cs in acc.items():
+        f = cs.get("FETCH_SIZE", [0.0, 1]); w = cs.get("WRITE_SIZE", [0.0, 1]); b = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0, 1])
+        # gfx950: FETCH_SIZE is in KiB and reports half of wide coalesced reads (x2); WRITE_SIZE in KiB is exact
+        out[name] = {"hbm_bytes": round(2.0 * f[0] / max(f[1], 1) * 1024.0 + w[0] / max(w[1], 1) * 1024.0), "mfma_busy": b[0] / max(b[1], 1)}
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +125,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-oracle steps (~1.8 s each at B=16 on 16 cores: ~11 s bounded sample)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy then come from the committed profiles/)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sustained-steps", type=int, default=300, help="extra untimed-by-the-contract leg: the same step for this many more iterations (steady-state clocks); 0 = skip")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
@@ -132,6 +180,12 @@ def main():
     warnings.simplefilter("ignore")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+    if args.pmc_child:  # the profiled child: a few steps of the workload, nothing else
+        args.steps, args.warmup, args.sustained_steps, args.no_cpu_baseline, args.no_roofline, args.no_live_pmc = 4, 2, 0, True, True, True
+    pmc_live = None
+    if not (args.no_live_pmc or args.no_roofline) and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
+        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe]
+        pmc_live = live_pmc(wl)  # before this process makes any GPU call
     from mvp import dist as mdist
 
     rank, local, world = mdist.env_setup("nccl")
@@ -292,15 +346,22 @@ def main():
         achieved = fl / sec / 1e12
         name = f"gemm_kernel<{tile}>" if kind == "gemm" else "attention_kernel"
         default_wl = (B, H, W, args.precision, args.probe) == (16, 224, 224, "bf16x3", "linear")
-        traffic, traffic_src = pmc_traffic(name) if default_wl else (None, None)
-        busy = pmc_mfma_busy(name) if default_wl else None
+        traffic, traffic_src, busy = None, None, None
+        if pmc_live:
+            hit = [v for k, v in pmc_live.items() if k.startswith(name.rstrip(">"))]
+            if hit:
+                traffic, busy, traffic_src = hit[0]["hbm_bytes"], hit[0]["mfma_busy"] or None, "live: rocprofv3 --pmc child passes of this invocation"
+        if traffic is None and default_wl:
+            traffic, traffic_src = pmc_traffic(name)
+            busy = pmc_mfma_busy(name)
+            traffic_src = f"committed pass {traffic_src}"
         clk = 2.1e9  # clock the chip holds under this load (in-kernel s_memtime / s_memrealtime)
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
-            "traffic": traffic, "traffic_unit": f"bytes/launch (memory-side, rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE; committed pass {traffic_src})",
+            "traffic": traffic, "traffic_unit": f"bytes/launch (memory-side, rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE; {traffic_src})",
             "mfma_busy": None if busy is None else {"SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy,
                                                     "frac_of_simd_cycles": round(busy / (1024 * (sec / cnt) * clk), 3),
-                                                    "note": "committed PMC pass; 1024 SIMDs x live launch duration x 2.1 GHz"},
+                                                    "note": "PMC pass (see traffic_unit); 1024 SIMDs x live launch duration x 2.1 GHz"},
             "hbm_kernels": {k[1]: {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2), "alg_mbytes_per_launch": round(v[0] / v[2] / 1e6, 2),
                                    "achieved_gbps": round(v[0] / v[1] / 1e9, 1), "frac_of_8TBps": round(v[0] / v[1] / 8e12, 3)} for k, v in hbm.items()},
             "kernel": name, "launches_per_step": cnt // nrep, "avg_launch_us": round(sec / cnt * 1e6, 2),
