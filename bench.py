@@ -81,7 +81,8 @@ def live_pmc(extra_args):
     import tempfile
 
     rp = shutil.which("rocprofv3")
-    if rp is None:
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rp is None or under_profiler:  # (a profiled parent already holds the GPU: no nested profiler runs)
         return None
     me = os.path.abspath(__file__)
     acc = {}
