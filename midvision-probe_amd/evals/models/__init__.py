@@ -5,3 +5,6 @@ from .dino import DINO  # noqa: F401
 from .ibot import iBOT  # noqa: F401
 from .mae import MAE  # noqa: F401
 from .mocov3 import MoCoV3  # noqa: F401
+from . import ssl_resnet50 as _ssl  # noqa: E402
+
+_ssl.register(__name__)  # evals.models.{barlowtwins, byol, ..., swav}: one table, fourteen importable sub-modules
