@@ -112,7 +112,8 @@ typedef struct {
    * read as the im2col of its (nearest-upsampled by 2^cup) [B, cH, cW, cC] view; K = ckh*ckw*cC with
    * k = (ky*ckw + kx)*cC + c (weights laid out [N, ckh, ckw, cC]); M = B*cHo*cWo; cC % 32 == 0.
    * Replaces nn.Conv2d 3x3 / strided convs of probes.py:283-306,318-375 and the ResNet trunk
-   * (dino_res50.py:38-51); padding taps read the caller's zero page (>= 256 zero bytes).           */
+   * (dino_res50.py:38-51); padding taps are read as out-of-range buffer offsets (zeros); the activation must
+   * stay below 2 GiB; zero_page (>= 256 zero bytes) is still validated for ABI stability but no longer read.  */
   int conv, cH, cW, cC, cHo, cWo, ckh, ckw, cstride, cpad, cup;
   const mvp_bf16* zero_page;
   /* --- ReLU bookkeeping (byte masks, row stride ldm):
@@ -385,7 +386,7 @@ int mvp_upsample_nearest_cl(const mvp_upsample_cl_args*, void* stream);
  * ---------------------------------------------------------------------------------- */
 typedef struct {
   const mvp_bf16* g_hi; const mvp_bf16* g_lo; const mvp_bf16* x_hi; const mvp_bf16* x_lo;
-  float* partial; float* dw; const mvp_bf16* zero_page; /* >= 512 zero bytes */
+  float* partial; float* dw; const mvp_bf16* zero_page; /* >= 512 zero bytes (ABI stability: no longer read, padding = out-of-range offsets) */
   int64_t M; int Cout, Cin, ldg, ldx;
   int H, W, Ho, Wo, kh, kw, stride, pad, up;
   int splits, accumulate, precision;
