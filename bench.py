@@ -90,9 +90,19 @@ def live_pmc(extra_args):
         for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"]):
             d = tempfile.mkdtemp(prefix="mvp_pmc_")
             cmd = [rp, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, me, *extra_args, "--pmc-child"]
-            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, cwd=tempfile.gettempdir(), env=dict(os.environ, TMPDIR=tempfile.gettempdir()))
+            # own session: on a timeout the whole group (rocprofv3 wrapper AND the profiled python) is ended, nothing is left on the GPU
+            pr = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=tempfile.gettempdir(),
+                                  env=dict(os.environ, TMPDIR=tempfile.gettempdir()), start_new_session=True)
+            try:
+                pr.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                import signal
+
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return None
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
-            if r.returncode != 0 or not files:
+            if pr.returncode != 0 or not files:
                 return None
             for path in files:
                 for row in csv.DictReader(open(path)):
