@@ -70,6 +70,7 @@ class FlatAdamW(torch.optim.Optimizer):
         off = 0
         for p, sz in zip(plist, sizes):
             _GRAD_DST[id(p)] = (self.flat_grad, off, p.numel(), tuple(p.shape), weakref.ref(p))
+            weakref.finalize(p, _GRAD_DST.pop, id(p), None)  # the table must not keep a dead optimiser's flat buffer alive
             off += sz
         self._params = plist
         self._n = total
