@@ -212,3 +212,37 @@ def test_trajectory_independent_of_host_syncs(dev):
         finals.append((torch.stack(losses).cpu(), probe.head.conv.weight.detach().clone(), probe.head.conv.bias.detach().clone()))
     assert torch.equal(finals[0][0], finals[1][0])
     assert torch.equal(finals[0][1], finals[1][1]) and torch.equal(finals[0][2], finals[1][2])
+
+
+def test_probe_training_reduces_loss_on_a_learnable_task(dev):
+    """Behavioural check of the whole loop (beyond parity): a linear bindepth probe on a frozen tiny ViT, trained for 150 steps on
+    images whose depth target is a smooth function of the image itself, must bring DepthLoss down substantially."""
+    import torch.nn.functional as F
+    from evals.models.dino import DINO
+    from evals.models.probes import DepthHead
+    from evals.utils.losses import DepthLoss
+    from evals.utils.optim import cosine_decay_linear_warmup
+    from mvp.optim import FlatAdamW
+    from mvp.train import train_depth_step
+    from oracle import vit as ovit
+
+    vsd = ovit.make_vit_weights(embed_dim=128, depth=4, seed=5)
+    model = DINO(return_multilayer=True, add_norm=True, weights=vsd).to(dev)
+    torch.manual_seed(0)
+    probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth").to(dev)
+    opt = FlatAdamW([{"params": probe.parameters(), "lr": 2e-3}])
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 150, 10))
+    g = torch.Generator().manual_seed(1)
+    batches = []
+    for _ in range(8):
+        img = torch.randn(4, 3, 64, 64, generator=g)
+        depth = 5.0 + 3.0 * torch.tanh(F.avg_pool2d(img.mean(1, keepdim=True), 16).repeat_interleave(16, 2).repeat_interleave(16, 3))  # in (2, 8)
+        batches.append((img.to(dev), depth.to(dev)))
+    loss_fn = DepthLoss()
+    losses = []
+    for s in range(150):
+        img, tgt = batches[s % len(batches)]
+        losses.append(train_depth_step(model, probe, opt, sched, loss_fn, img, tgt.clone()))
+    losses = torch.stack(losses).cpu()
+    first, last = losses[:8].mean().item(), losses[-8:].mean().item()
+    assert torch.isfinite(losses).all() and last < 0.6 * first, (first, last)
