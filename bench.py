@@ -139,6 +139,8 @@ def parse_args():
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy then come from the committed profiles/)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sustained-steps", type=int, default=300, help="extra untimed-by-the-contract leg: the same step for this many more iterations (steady-state clocks); 0 = skip")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("MVP_INFLIGHT", "2")),
+                    help="frozen-backbone forwards kept in flight on side HIP streams (mvp/pipeline.py); 1 = one serial kernel chain")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
 
@@ -193,6 +195,7 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if args.pmc_child:  # the profiled child: a few steps of the workload, nothing else
         args.steps, args.warmup, args.sustained_steps, args.no_cpu_baseline, args.no_roofline, args.no_live_pmc = 4, 2, 0, True, True, True
+        args.inflight = 1  # per-kernel counters: one kernel on the chip at a time
     pmc_live = None
     if not (args.no_live_pmc or args.no_roofline) and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
         wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe]
@@ -254,6 +257,23 @@ def main():
         images, target = batches[i % n_distinct]
         return train_depth_step(model, probe, opt, sched, loss_fn, images, target)
 
+    from mvp.pipeline import FeaturePipeline
+
+    pipe = FeaturePipeline(model, args.inflight)
+
+    def run_steps(i0, n, out=None, pipe=pipe):
+        """Steps i0 .. i0+n-1, every one the full train_depth.py:99-143 body.  Up to ``inflight`` frozen forwards are in flight on side
+        streams while the probe steps run in order on this stream; the pipeline starts empty and ends empty, so all the work of these n
+        steps (n forwards, n probe forward/backward/AdamW) lies between the caller's two barriers."""
+        nxt = i0
+        for i in range(i0, i0 + n):
+            while len(pipe) < pipe.depth and nxt < i0 + n:
+                pipe.submit(batches[nxt % n_distinct][0])
+                nxt += 1
+            loss = train_depth_step(model, probe, opt, sched, loss_fn, None, batches[i % n_distinct][1], feats=pipe.next())
+            if out is not None:
+                out.append(loss)
+
     def barrier():
         opt.finish_pending()  # the last step's update belongs to the timed region
         if world > 1:
@@ -261,12 +281,10 @@ def main():
         torch.cuda.synchronize()
 
     losses = []  # device scalars, reduced after the timed region (no accumulate kernel inside it, no host sync per step)
-    for i in range(args.warmup):
-        losses.append(step(i))
+    run_steps(0, args.warmup, losses)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        losses.append(step(args.warmup + i))
+    run_steps(args.warmup, args.steps, losses)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -277,13 +295,31 @@ def main():
     loss_acc = torch.zeros((), device=dev)
     images_per_s = world * B * args.steps / dt
 
+    # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
+    pipeline_info = {"inflight": pipe.depth,
+                     "what": "frozen forwards of upcoming batches run on side HIP streams under the probe step of the current batch; "
+                             "every step still runs its own full forward + probe forward/backward/AdamW inside the timed region"}
+    if pipe.depth > 1:
+        serial_pipe = FeaturePipeline(model, 1)
+        barrier()
+        ts = time.perf_counter()
+        run_steps(args.warmup + args.steps, args.steps, None, serial_pipe)
+        barrier()
+        sdt1 = time.perf_counter() - ts
+        if world > 1:
+            tm = torch.tensor([sdt1], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            sdt1 = float(tm.item())
+        pipeline_info["serial"] = {"steps": args.steps, "value": round(world * B * args.steps / sdt1, 2), "unit": "images/s",
+                                   "ms_per_step": round(sdt1 / args.steps * 1e3, 4)}
+
     # ---------------- sustained leg (reported next to `value`, never instead of it): a short run sits in boost clocks
     sustained = None
     if args.sustained_steps > 0:
         barrier()
         t1 = time.perf_counter()
-        for i in range(args.sustained_steps):
-            step(args.warmup + args.steps + i)
+        run_steps(args.warmup + args.steps, args.sustained_steps)
+        host_dt = time.perf_counter() - t1  # host enqueue time of the leg (the device runs behind it)
         barrier()
         sdt = time.perf_counter() - t1
         if world > 1:
@@ -291,7 +327,7 @@ def main():
             torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
             sdt = float(tm.item())
         sustained = {"steps": args.sustained_steps, "value": round(world * B * args.sustained_steps / sdt, 2), "unit": "images/s",
-                     "ms_per_step": round(sdt / args.sustained_steps * 1e3, 4)}
+                     "ms_per_step": round(sdt / args.sustained_steps * 1e3, 4), "host_enqueue_ms_per_step": round(host_dt / args.sustained_steps * 1e3, 4)}
 
     # ---------------- optional PCIe-inclusive leg (never `value`): the same steps fed from HOST memory
     h2d = None
@@ -377,7 +413,8 @@ def main():
                                    "achieved_gbps": round(v[0] / v[1] / 1e9, 1), "frac_of_8TBps": round(v[0] / v[1] / 8e12, 3)} for k, v in hbm.items()},
             "kernel": name, "launches_per_step": cnt // nrep, "avg_launch_us": round(sec / cnt * 1e6, 2),
             "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
-            "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop); HIP events on the launch stream",
+            "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop); HIP events on the launch stream, taken in 3 extra "
+                    "steps run as ONE serial chain (inflight 1) so a launch duration is the kernel alone on the chip, as in a rocprofv3 trace of --inflight 1",
             "all_kernels": {f"{k[0]}:{k[1]}": {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2),
                                                 "alg_tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in groups.items()},
             "whole_step_alg_tflops": round(images_per_s / world * f_img / 1e12, 2),
@@ -440,6 +477,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
                        "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
             "mean_loss": round(last_loss, 5),
+            "pipeline": pipeline_info,
             "sustained": sustained,
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_config1": cpu1, **({"h2d_inclusive": h2d} if h2d else {}),
         }

@@ -88,7 +88,7 @@ def patch_gather(images: torch.Tensor, out: Pair, P: int, gh: int, gw: int, pad_
     lib.call("mvp_patch_gather", a)
 
 
-_SPLITK_WS = {}  # device -> zero-initialised workspace (tile counters reset themselves; one stream at a time)
+_SPLITK_WS = {}  # (device, stream) -> zero-initialised workspace (tile counters reset themselves)
 
 
 def splitk_auto(M: int, N: int, K: int) -> int:
@@ -102,7 +102,7 @@ def splitk_auto(M: int, N: int, K: int) -> int:
     return 1
 
 
-_STREAMK_WS = {}  # device -> zero-initialised stream-K workspace (tile counters reset themselves; one stream at a time)
+_STREAMK_WS = {}  # (device, stream) -> zero-initialised stream-K workspace (tile counters reset themselves)
 _STREAMK_MODE = os.environ.get("MVP_STREAMK", "auto")  # "auto" | "0" | "1" (diagnostic override)
 
 
@@ -115,18 +115,25 @@ def streamk_auto(M: int, N: int, K: int, precision: int) -> bool:
     return _STREAMK_MODE == "1"
 
 
+def _ws_key(device):
+    # launches on one stream are ordered, so they may share a workspace; launches on different streams (mvp/pipeline.py) may not
+    return (device, lib.stream_ptr())
+
+
 def _streamk_workspace(device) -> torch.Tensor:
-    ws = _STREAMK_WS.get(device)
+    key = _ws_key(device)
+    ws = _STREAMK_WS.get(key)
     if ws is None:
-        ws = _STREAMK_WS[device] = torch.zeros(int(lib.load().mvp_gemm_streamk_workspace_bytes()), dtype=torch.uint8, device=device)
+        ws = _STREAMK_WS[key] = torch.zeros(int(lib.load().mvp_gemm_streamk_workspace_bytes()), dtype=torch.uint8, device=device)
     return ws
 
 
 def _splitk_workspace(M: int, N: int, S: int, device) -> torch.Tensor:
     need = int(lib.load().mvp_gemm_splitk_workspace_bytes(M, N, S))
-    ws = _SPLITK_WS.get(device)
+    key = _ws_key(device)
+    ws = _SPLITK_WS.get(key)
     if ws is None or ws.numel() < need:
-        ws = _SPLITK_WS[device] = torch.zeros(max(need, 32 << 20), dtype=torch.uint8, device=device)
+        ws = _SPLITK_WS[key] = torch.zeros(max(need, 32 << 20), dtype=torch.uint8, device=device)
     return ws
 
 

@@ -1,0 +1,172 @@
+"""Frozen-backbone forwards in flight on side HIP streams.
+
+The backbone is frozen (train_depth.py:103-112 runs it under no_grad and detaches), so the features of batch t+1 do not
+depend on probe step t.  ``FeaturePipeline`` launches each forward on one of ``depth`` side streams as soon as its batch is
+known; the trainer's stream picks the features up with an event wait.  Two independent kernel chains then share the chip: the
+GEMM tiles of one fill the CUs the other leaves idle (600 tiles on 256 CUs), and a chain's LayerNorm / attention / probe
+kernels run under the other's GEMMs.  Measured on MI355X (tools/micro/two_stream_probe.py, ViT-B/16 4-tap forward, B=16
+each): two forwards back to back 5.34 ms, the same two on two streams 4.61 ms.
+
+Nothing about the arithmetic changes: every batch still runs alone through the same kernels with its own tap-BN batch
+statistics, and the tap-BN running statistics are updated in batch order (ViTEngine orders tap j of forward t+1 after tap j
+of forward t with an event).  A pipelined run is bit-identical to the serial one (tests/test_gpu_pipeline.py).
+
+Each in-flight forward owns a *slot*: the engine keeps one activation workspace, one token-major feature packing and one set
+of output maps per slot, so a forward never writes buffers the probe step of an earlier batch is still reading, and the steady
+state allocates nothing.  A slot is reused only after the trainer's stream has passed the probe step that consumed it
+(``submit`` makes the side stream wait for the trainer's stream).  Contract: the features ``next()`` returns are valid until
+``depth`` further forwards have been submitted — consume them (probe forward + backward) before feeding the pipeline again, as
+``pipelined_features`` does; ``.clone()`` anything that must live longer.
+"""
+from __future__ import annotations
+
+import collections
+import contextlib
+import os
+from typing import Iterable, Iterator, Tuple
+
+import torch
+
+_SLOT = 0  # slot of the forward being enqueued (host state; kernels are enqueued by one host thread)
+_PIPELINED = False
+
+
+def current_slot() -> int:
+    return _SLOT
+
+
+def pipelined() -> bool:
+    """True while a forward is being enqueued on a pipeline side stream."""
+    return _PIPELINED
+
+
+@contextlib.contextmanager
+def _slot(i: int):
+    global _SLOT, _PIPELINED
+    prev = (_SLOT, _PIPELINED)
+    _SLOT, _PIPELINED = i, True
+    try:
+        yield
+    finally:
+        _SLOT, _PIPELINED = prev
+
+
+def default_depth() -> int:
+    """Forwards kept in flight by the trainers and bench.py (MVP_INFLIGHT, default 2; 1 = everything on the trainer's stream)."""
+    return max(1, int(os.environ.get("MVP_INFLIGHT", "2")))
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors(o)
+        for name in ("cls", "stats"):  # TapOutputs side products allocated by the forward
+            extra = getattr(obj, name, None)
+            if extra is not None and extra is not obj:
+                yield from _tensors(extra)
+
+
+class FeaturePipeline:
+    """``submit(images)`` enqueues ``model(images)`` on a side stream; ``next()`` returns the oldest submitted features on the
+    caller's current stream (event wait, no host sync).  ``depth`` = forwards in flight; backbones whose engine does not keep
+    per-slot buffers (``supports_pipelining`` False) run inline on the caller's stream, as does depth 1."""
+
+    def __init__(self, model, depth: int = None, run_ahead: int = None):
+        """``run_ahead``: the host may be at most this many forwards ahead of the device (MVP_RUN_AHEAD, default 8; 0 = unbounded).
+        The reference's loop syncs every step (``loss.item()``, train_depth.py:143); a loop that never syncs would otherwise queue
+        hundreds of launches (and keep their argument buffers alive).  Throughput-neutral on MI355X (tools/micro/pipeline_probe.py,
+        B=16, 300 steps, 2 in flight: 6526 img/s unbounded, 6565 with 8, 6584 with 3)."""
+        depth = default_depth() if depth is None else int(depth)
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        if not getattr(model, "supports_pipelining", False):
+            depth = 1
+        self.model, self.depth = model, depth
+        self.streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else []
+        self._queue = collections.deque()
+        self._n = 0
+        self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
+        self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
+
+    def __len__(self) -> int:
+        return len(self._queue)
+
+    def submit(self, images: torch.Tensor) -> None:
+        if len(self._queue) >= self.depth:
+            raise RuntimeError(f"{self.depth} forwards already in flight: call next() first")
+        from .train import extract_features
+
+        if self.run_ahead > 0 and len(self._issued) >= self.run_ahead:
+            self._issued.popleft().synchronize()  # host waits for the forward issued ``run_ahead`` submissions ago
+        if self.depth == 1:
+            feats = extract_features(self.model, images)
+            if self.run_ahead > 0 and images.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self._issued.append(ev)
+            self._queue.append((feats, None))
+            return
+        slot = self._n % self.depth
+        self._n += 1
+        s = self.streams[slot]
+        cur = torch.cuda.current_stream()
+        # the batch is ready on the caller's stream, and the probe step that read this slot's buffers is already enqueued there
+        s.wait_stream(cur)
+        with torch.cuda.stream(s), _slot(slot):
+            feats = extract_features(self.model, images)
+            done = torch.cuda.Event()
+            done.record(s)
+        if self.run_ahead > 0:
+            self._issued.append(done)
+        if images.is_cuda:
+            images.record_stream(s)  # allocated on the caller's stream, read on the side stream
+        self._queue.append((feats, done))
+
+    def next(self):
+        feats, done = self._queue.popleft()
+        if done is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
+            for t in _tensors(feats):
+                t.record_stream(cur)  # allocated on the side stream, read (and later freed) under the caller's stream
+        return feats
+
+    def drain(self) -> None:
+        while self._queue:
+            self.next()
+
+
+def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None) -> Iterator[Tuple[object, object]]:
+    """Yield ``(batch, features)`` for every batch of ``batches`` with up to ``depth`` forwards in flight: the forward of batch
+    t+1 is enqueued before batch t is handed to the caller, so it runs under the caller's probe step t."""
+    pipe = FeaturePipeline(model, depth)
+    it = iter(batches)
+    pending = collections.deque()
+
+    def images_of(b):
+        x = b[image_key] if isinstance(b, dict) else b[0]
+        if x.is_cuda or not torch.cuda.is_available():  # (a host tensor without a device: the backbone raises MvpError)
+            return x
+        return x.to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
+
+    def feed() -> bool:
+        try:
+            b = next(it)
+        except StopIteration:
+            return False
+        pipe.submit(images_of(b))
+        pending.append(b)
+        return True
+
+    try:
+        while True:
+            while len(pipe) < pipe.depth and feed():
+                pass
+            if not pending:
+                break
+            b = pending.popleft()
+            yield b, pipe.next()
+    finally:
+        pipe.drain()

@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import functional as MF
+from .pipeline import pipelined_features
 
 
 def extract_features(model, images, detach_model=True):
@@ -34,11 +35,13 @@ def _finish_pending(optimizer):
         fin()
 
 
-def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model=True, scale_invariant=False):
+def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model=True, scale_invariant=False, feats=None):
     """One iteration of train_depth.py:99-143; returns the loss as a DEVICE scalar (the
-    reference's per-step ``loss.item()`` host sync is left to the caller)."""
+    reference's per-step ``loss.item()`` host sync is left to the caller).  ``feats``: the frozen features of ``images`` when
+    the caller already has them in flight (mvp/pipeline.py); None runs the backbone here."""
     optimizer.zero_grad()
-    feats = extract_features(model, images, detach_model)
+    if feats is None:
+        feats = extract_features(model, images, detach_model)
     _finish_pending(optimizer)
     pred = probe(feats)
     pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
@@ -54,12 +57,14 @@ def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target
     return loss.detach()
 
 
-def train_snorm_step(model, probe, optimizer, scheduler, images, target, mask, detach_model=True):
-    """One iteration of train_snorm.py:93-120 (bicubic upsample, angular loss, UA iff 4 channels)."""
+def train_snorm_step(model, probe, optimizer, scheduler, images, target, mask, detach_model=True, feats=None):
+    """One iteration of train_snorm.py:93-120 (bicubic upsample, angular loss, UA iff 4 channels).  ``feats`` as in
+    ``train_depth_step``."""
     from evals.utils.losses import angular_loss
 
     optimizer.zero_grad()
-    feats = extract_features(model, images, detach_model)
+    if feats is None:
+        feats = extract_features(model, images, detach_model)
     _finish_pending(optimizer)
     pred = probe(feats)
     pred = MF.interpolate(pred.contiguous(), size=target.shape[-2:], mode="bicubic")
@@ -93,10 +98,12 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
         if world_size > 1 and hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
             train_loader.sampler.set_epoch(ep)
         train_loss = 0.0
-        for i, batch in enumerate(_device_batches(train_loader, dev)):
-            images = batch["image"].to(dev, non_blocking=True)
+        if not detach_model:
+            extract_features(model, None, detach_model)  # raises: backbone fine-tuning is outside the frozen hot path
+        # the frozen forward of batch t+1 is already in flight (side stream) while the probe step of batch t runs
+        for i, (batch, feats) in enumerate(pipelined_features(model, _device_batches(train_loader, dev))):
             target = batch["depth"].to(dev, non_blocking=True).contiguous()
-            loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target, detach_model, scale_invariant)
+            loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, None, target, detach_model, scale_invariant, feats=feats)
             train_loss += loss.item()  # the reference syncs every step too (train_depth.py:143)
         history.append(train_loss / max(len(train_loader), 1))
     return history

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
-from . import lib, ops
+from . import lib, ops, pipeline
 from .lib import PREC_BF16, PREC_BF16X3
 
 
@@ -58,6 +58,7 @@ class PackedFeatures:
 
 
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
+_PACK_REGISTRY_MAX = 4
 
 
 def _ver(t: torch.Tensor) -> int:
@@ -73,8 +74,13 @@ def register_pack(maps: Sequence[torch.Tensor], pack: PackedFeatures) -> None:
     version 0 (re-uploaded cached features, clones), which would then silently alias this packing."""
     pack.sources = [(m.data_ptr(), _ver(m)) for m in maps]
     pack.source_refs = list(maps)
-    _PACK_REGISTRY.clear()  # single most-recent entry: the probe consumes features right after the backbone
+    # one entry per packing buffer: the probe consumes features right after the backbone, or — with several forwards in flight
+    # (mvp/pipeline.py) — one entry per pipeline slot.  Entries of other engines / shapes age out beyond the newest few.
+    for k in [k for k, v in _PACK_REGISTRY.items() if v is pack]:
+        del _PACK_REGISTRY[k]
     _PACK_REGISTRY[maps[0].data_ptr()] = pack
+    while len(_PACK_REGISTRY) > _PACK_REGISTRY_MAX:
+        del _PACK_REGISTRY[next(iter(_PACK_REGISTRY))]
 
 
 def lookup_pack(maps: Sequence[torch.Tensor]) -> Optional[PackedFeatures]:
@@ -123,13 +129,15 @@ class ViTEngine:
             )
             self.blocks.append(blk)
         self.hidden = self.blocks[0]["fc1_b"].numel()
-        self._ws: Dict[Tuple[int, int, int], dict] = {}
+        self._ws: Dict[Tuple[int, int, int, int], dict] = {}  # (B, gh, gw, pipeline slot)
         self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
-        self._packs: Dict[Tuple[int, int, int, int], PackedFeatures] = {}
+        self._packs: Dict[Tuple[int, int, int, int, int], PackedFeatures] = {}
+        self._slot_outs: Dict[tuple, dict] = {}  # output maps of pipelined forwards, owned by the slot
+        self._tap_events: Dict[int, torch.cuda.Event] = {}  # tap index -> "running statistics updated" of the latest pipelined forward
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, B: int, gh: int, gw: int) -> dict:
-        key = (B, gh, gw)
+        key = (B, gh, gw, pipeline.current_slot())
         ws = self._ws.get(key)
         if ws is None:
             N = 1 + gh * gw
@@ -144,7 +152,8 @@ class ViTEngine:
                 patches=ops.empty_pair((B * gh * gw, self.in_chans * self.patch * self.patch), pr, dev),
                 bn_ws=torch.empty(ops.bn_tokens_workspace_bytes(M, C) // 4 + 16, dtype=torch.float32, device=dev),
             )
-            self._ws = {key: ws}  # keep one resolution resident
+            self._ws = {k: v for k, v in self._ws.items() if k[:3] == key[:3]}  # keep one resolution resident (one buffer set per slot)
+            self._ws[key] = ws
         return ws
 
     def pos_for(self, gh: int, gw: int, dim2: int, dim3: int) -> torch.Tensor:
@@ -219,19 +228,51 @@ class ViTEngine:
         outs = TapOutputs()
         packed = None
         if pack:  # reuse the (zero padded) packing buffers across steps: only the valid region is rewritten
-            pkey = (B, gh, gw, len(layers))
+            pkey = (B, gh, gw, len(layers), pipeline.current_slot())
             packed = self._packs.get(pkey)
             if packed is None:
                 packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device)
-                self._packs = {pkey: packed}
+                self._packs = {k: v for k, v in self._packs.items() if k[:4] == pkey[:4]}
+                self._packs[pkey] = packed
             packed.generation += 1
-        stats = torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device)
+        # Plain calls return freshly allocated maps (the caller may keep them).  A pipelined forward (mvp/pipeline.py) writes into
+        # buffers owned by its slot instead — valid until the slot's next forward, which is the pipeline's contract — so the
+        # steady state allocates nothing and no block ever changes hands between the side stream's and the trainer's allocator pools.
+        slot_out = None
+        if pipeline.pipelined():
+            okey = (B, gh, gw, tuple(layers), bool(want_cls), pipeline.current_slot())
+            slot_out = self._slot_outs.get(okey)
+            if slot_out is None:
+                slot_out = dict(stats=torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device),
+                                nchw=[torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device) for _ in layers],
+                                cls=[torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None for _ in layers])
+                self._slot_outs = {k: v for k, v in self._slot_outs.items() if k[:5] == okey[:5]}
+                self._slot_outs[okey] = slot_out
+        stats = slot_out["stats"] if slot_out else torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device)
 
         outs.cls = []
 
+        # Train-mode tap BN updates its running statistics in place.  With several forwards in flight on different streams those
+        # read-modify-writes must happen in batch order: tap j waits for tap j of the previous forward (an event per tap).
+        order_taps = bn is not None and bn_mode == 0 and (pipeline.pipelined() or bool(self._tap_events))
+
         def tap(j):
-            nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
-            cls = torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None
+            if order_taps:
+                prev = self._tap_events.pop(j, None)
+                if prev is not None:
+                    torch.cuda.current_stream().wait_event(prev)
+            tap_kernel(j)
+            if order_taps and pipeline.pipelined():
+                ev = torch.cuda.Event()
+                ev.record()
+                self._tap_events[j] = ev
+
+        def tap_kernel(j):
+            if slot_out:
+                nchw, cls = slot_out["nchw"][j], slot_out["cls"][j]
+            else:
+                nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
+                cls = torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None
             if want_cls:
                 outs.cls.append(cls)
             b = bn[j] if bn is not None else None

@@ -14,6 +14,7 @@ import torch  # noqa: E402
 from mvp import checkpoint, config  # noqa: E402
 from mvp import dist as mdist  # noqa: E402
 from mvp.optim import FlatAdamW  # noqa: E402
+from mvp.pipeline import pipelined_features  # noqa: E402
 from mvp.train import train_snorm_step  # noqa: E402
 
 
@@ -44,10 +45,10 @@ def main(argv):
         tot = 0.0
         if world > 1:
             loader.sampler.set_epoch(ep)
-        for batch in DevicePrefetcher(loader, dev):
-            images, target = batch["image"], batch["snorm"]
+        for batch, feats in pipelined_features(model, DevicePrefetcher(loader, dev)):  # forward of the next batch already in flight
+            target = batch["snorm"]
             mask = batch["depth"] > 0                               # train_snorm.py:95
-            tot += train_snorm_step(model, probe, opt, sched, images, target, mask).item()
+            tot += train_snorm_step(model, probe, opt, sched, None, target, mask, feats=feats).item()
         if rank == 0:
             print(f"epoch {ep} train loss {tot / nb:.4f}")
     opt.finish_pending()

@@ -1,0 +1,130 @@
+"""Frozen forwards in flight on side streams (mvp/pipeline.py) must not change a single bit of the training trajectory:
+the same batches through ``train_depth_step`` as one serial chain and with 2 / 3 forwards in flight give identical losses,
+probe weights, AdamW state and tap-BN running statistics (those are updated in place by every forward, in batch order).
+Reference semantics: train_depth.py:99-143 (one batch at a time; the backbone is frozen, so its forward of batch t+1 does not
+depend on probe step t)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(dev, probe_kind="linear"):
+    from evals.models.dino import DINO
+    from evals.models.probes import DepthHead
+    from evals.utils.optim import cosine_decay_linear_warmup
+    from mvp import backbone as bb
+    from mvp.optim import FlatAdamW
+
+    model = DINO(return_multilayer=True, add_norm=True, weights=bb.random_vit_state_dict(seed=3)).to(dev)
+    torch.manual_seed(11)
+    if probe_kind == "linear":
+        probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth", min_depth=0.001, max_depth=10).to(dev)
+    else:
+        probe = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=128, min_depth=0.001, max_depth=10).to(dev)
+    opt = FlatAdamW([{"params": probe.parameters(), "lr": 1e-3}])
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 100, 10))
+    return model, probe, opt, sched
+
+
+def _batches(dev, n, B=4, hw=(64, 80)):
+    out = []
+    for s in range(n):
+        g = torch.Generator().manual_seed(500 + s)
+        img = torch.randn(B, 3, *hw, generator=g)
+        dep = torch.rand(B, 1, *hw, generator=g) * 9.0 + 0.05
+        out.append({"image": img.to(dev), "depth": dep.to(dev)})
+    return out
+
+
+def _run(depth, probe_kind="linear", n=7):
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import pipelined_features
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    model, probe, opt, sched = _build(dev, probe_kind)
+    loss_fn = DepthLoss()
+    losses = []
+    for batch, feats in pipelined_features(model, _batches(dev, n), depth=depth):
+        losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, batch["depth"].clone(), feats=feats))
+    torch.cuda.synchronize()
+    bn = [torch.cat([b.running_mean, b.running_var]).cpu().numpy() for b in model.batchnorms]
+    nbt = [int(b.num_batches_tracked) for b in model.batchnorms]
+    return (torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(), opt.exp_avg_sq.cpu().numpy().copy(), bn, nbt)
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_pipelined_training_is_bit_identical_to_serial(depth):
+    ref = _run(1)
+    got = _run(depth)
+    assert np.isfinite(ref[0]).all() and ref[4] == [7] * 4
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    for a, b in zip(got[3], ref[3]):
+        np.testing.assert_array_equal(a, b)
+    assert got[4] == ref[4]
+
+
+def test_pipelined_dpt_probe_is_bit_identical_to_serial():
+    ref = _run(1, "dpt", n=4)
+    got = _run(2, "dpt", n=4)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_pipeline_matches_plain_step_and_mixes_with_direct_calls():
+    """pipelined_features == calling train_depth_step(images) batch by batch; a direct model(images) after a pipelined stretch
+    sees the running statistics of every earlier forward (event order), and eval-mode forwards still work."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import FeaturePipeline
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    bs = _batches(dev, 5)
+    model, probe, opt, sched = _build(dev)
+    loss_fn = DepthLoss()
+    plain = [train_depth_step(model, probe, opt, sched, loss_fn, b["image"], b["depth"].clone()) for b in bs]
+    ref_rm = model.batchnorms[0].running_mean.clone()
+    ref_w = opt.flat_param.clone()
+
+    model, probe, opt, sched = _build(dev)
+    pipe = FeaturePipeline(model, 2)
+    assert pipe.depth == 2
+    got = []
+    pipe.submit(bs[0]["image"])
+    pipe.submit(bs[1]["image"])
+    with pytest.raises(RuntimeError):
+        pipe.submit(bs[2]["image"])
+    for i in range(3):
+        got.append(train_depth_step(model, probe, opt, sched, loss_fn, None, bs[i]["depth"].clone(), feats=pipe.next()))
+        if i == 0:
+            pipe.submit(bs[2]["image"])
+    assert len(pipe) == 0
+    for b in bs[3:]:  # back to the plain path on the caller's stream
+        got.append(train_depth_step(model, probe, opt, sched, loss_fn, b["image"], b["depth"].clone()))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(torch.stack(got).cpu().numpy(), torch.stack(plain).cpu().numpy())
+    assert torch.equal(model.batchnorms[0].running_mean, ref_rm)
+    assert torch.equal(opt.flat_param, ref_w)
+    model.eval()
+    with torch.no_grad():
+        f = model(bs[0]["image"])
+    assert all(torch.isfinite(t).all() for t in f)
+
+
+def test_backbones_without_slots_run_inline():
+    """ResNet engines keep no per-slot buffers: the pipeline degrades to the caller's stream (depth 1) instead of racing."""
+    from evals.models.dino_res50 import DINO_RESNET
+    from mvp.pipeline import FeaturePipeline
+
+    dev = torch.device("cuda:0")
+    model = DINO_RESNET(return_layers=[1, 2, 3, 4], return_multilayer=True, add_norm=True, fixed_size=96).to(dev)
+    pipe = FeaturePipeline(model, 2)
+    assert pipe.depth == 1 and pipe.streams == []
+    x = torch.randn(2, 3, 96, 96, device=dev)
+    pipe.submit(x)
+    a = pipe.next()
+    assert all(torch.isfinite(t).all() for t in a)
