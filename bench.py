@@ -139,8 +139,10 @@ def parse_args():
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy then come from the committed profiles/)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--sustained-steps", type=int, default=300, help="extra untimed-by-the-contract leg: the same step for this many more iterations (steady-state clocks); 0 = skip")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("MVP_INFLIGHT", "2")),
-                    help="frozen-backbone forwards kept in flight on side HIP streams (mvp/pipeline.py); 1 = one serial kernel chain")
+    ap.add_argument("--inflight", type=int, default=None,
+                    help="frozen-backbone forwards kept in flight on side HIP streams (mvp/pipeline.py); 1 = one serial kernel chain; "
+                         "default: mvp.pipeline.default_depth(probe) = what the trainers use (2 under the linear probe, 1 under DPT)")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra inflight=1 leg reported as pipeline.serial (profiling runs)")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
 
@@ -259,7 +261,9 @@ def main():
 
     from mvp.pipeline import FeaturePipeline
 
-    pipe = FeaturePipeline(model, args.inflight)
+    from mvp.pipeline import default_depth
+
+    pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else default_depth(probe))
 
     def run_steps(i0, n, out=None, pipe=pipe):
         """Steps i0 .. i0+n-1, every one the full train_depth.py:99-143 body.  Up to ``inflight`` frozen forwards are in flight on side
@@ -299,7 +303,7 @@ def main():
     pipeline_info = {"inflight": pipe.depth,
                      "what": "frozen forwards of upcoming batches run on side HIP streams under the probe step of the current batch; "
                              "every step still runs its own full forward + probe forward/backward/AdamW inside the timed region"}
-    if pipe.depth > 1:
+    if pipe.depth > 1 and not args.no_serial_leg:
         serial_pipe = FeaturePipeline(model, 1)
         barrier()
         ts = time.perf_counter()

@@ -7,7 +7,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from . import lib, ops
+from . import lib, ops, pipeline
 from .lib import PREC_BF16X3
 from .ops import Pair
 
@@ -18,6 +18,7 @@ def zero_page(dev) -> torch.Tensor:
     z = _ZERO.get(dev)
     if z is None:
         z = _ZERO[dev] = torch.zeros(512, dtype=torch.bfloat16, device=dev)
+        pipeline.publish()
     return z
 
 

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from . import lib, ops
+from . import lib, ops, pipeline
 from .lib import PREC_BF16, PREC_BF16X3
 from .vit import PackedFeatures, lookup_pack
 
@@ -332,6 +332,7 @@ def _one(dev) -> torch.Tensor:
     t = _ONE.get(dev)
     if t is None:
         t = _ONE[dev] = torch.ones((), dtype=torch.float32, device=dev)
+        pipeline.publish()
     return t
 
 

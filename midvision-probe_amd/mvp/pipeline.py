@@ -51,9 +51,44 @@ def _slot(i: int):
         _SLOT, _PIPELINED = prev
 
 
-def default_depth() -> int:
-    """Forwards kept in flight by the trainers and bench.py (MVP_INFLIGHT, default 2; 1 = everything on the trainer's stream)."""
-    return max(1, int(os.environ.get("MVP_INFLIGHT", "2")))
+def publish() -> None:
+    """Call once after building a long-lived device buffer that launches on ANY stream will read (split weights, resized
+    pos-embed, constant pages): its initialising kernels ran on the current stream only, and a forward on another stream could
+    otherwise read it early.  A device-wide sync, paid once per buffer."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class UpdateOrder:
+    """Keeps in-place updates of state shared by all forwards (the tap-BN running statistics, updated by every train-mode forward)
+    in batch order when forwards run on different streams: update ``key`` of forward t+1 waits for update ``key`` of forward t."""
+
+    def __init__(self):
+        self._events = {}
+
+    def before(self, key) -> None:
+        prev = self._events.pop(key, None)
+        if prev is not None:
+            torch.cuda.current_stream().wait_event(prev)
+
+    def after(self, key) -> None:
+        if _PIPELINED:  # a forward on the trainer's own stream is ordered by the stream itself
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[key] = ev
+
+
+def default_depth(probe=None) -> int:
+    """Forwards kept in flight by the trainers and bench.py.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).
+    Otherwise 2, except under a DPT probe: measured on MI355X at B=16 (bench.py, img/s, 1 -> 2 in flight) the linear probe gains
+    5440-5510 -> 6330-6640 at 224^2 and 1041 -> 1062 at 480x640 (B=64: 7403 -> 7598), while the DPT probe step — 19 ms of
+    chip-filling convolutions per batch — loses 739-748 -> 699-723 to the forward running beside it."""
+    env = os.environ.get("MVP_INFLIGHT")
+    if env is not None:
+        return max(1, int(env))
+    if probe is not None and "_dpt_" in str(getattr(probe, "name", "")):
+        return 1
+    return 2
 
 
 def _tensors(obj):
@@ -84,6 +119,7 @@ class FeaturePipeline:
         if not getattr(model, "supports_pipelining", False):
             depth = 1
         self.model, self.depth = model, depth
+        # (stream priorities do not help: the device offers only (0, -1), and high-priority side streams measured the same)
         self.streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else []
         self._queue = collections.deque()
         self._n = 0
@@ -138,10 +174,11 @@ class FeaturePipeline:
             self.next()
 
 
-def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None) -> Iterator[Tuple[object, object]]:
+def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None, probe=None) -> Iterator[Tuple[object, object]]:
     """Yield ``(batch, features)`` for every batch of ``batches`` with up to ``depth`` forwards in flight: the forward of batch
-    t+1 is enqueued before batch t is handed to the caller, so it runs under the caller's probe step t."""
-    pipe = FeaturePipeline(model, depth)
+    t+1 is enqueued before batch t is handed to the caller, so it runs under the caller's probe step t.  ``depth`` None:
+    ``default_depth(probe)``."""
+    pipe = FeaturePipeline(model, default_depth(probe) if depth is None else depth)
     it = iter(batches)
     pending = collections.deque()
 

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import conv as cv
-from . import lib, ops
+from . import lib, ops, pipeline
 from .vit import TapOutputs, parse_precision
 
 LAYERS = (3, 4, 6, 3)
@@ -62,6 +62,8 @@ class ResNetEngine:
                 stage.append(blk)
             self.blocks.append(stage)
         self.stage_channels = [self.c0] + [st[-1]["cout"] for st in self.blocks]
+        self._tap_order = pipeline.UpdateOrder()  # tap-BN running statistics are updated in batch order across streams
+        pipeline.publish()  # the folded / split weights are read by forwards on any stream
 
     # ------------------------------------------------------------------ stages (x = (fp32, pair), H, W)
     def _stem(self, images: torch.Tensor, want_f32: bool = False):
@@ -112,10 +114,12 @@ class ResNetEngine:
 
     # ------------------------------------------------------------------ forward
     def forward_taps(self, images: torch.Tensor, multilayers: Sequence[int], *, bn: Optional[Sequence[Optional[dict]]] = None,
-                     bn_mode: int = 0, want_tokens: bool = True) -> TapOutputs:
+                     bn_mode: int = 0, want_tokens: bool = False) -> TapOutputs:
         """images: [B,3,S,S] fp32 device (already resized).  Returns NCHW fp32 maps for the stage
         indices in ``multilayers`` (0 = stem+maxpool, 1..4 = layer1..4); ``outs.tokens[j]`` holds the
-        channels-last bf16 pair of tap j (operand of a conv head).  bn[i] is indexed by STAGE i."""
+        channels-last bf16 pair of tap j when ``want_tokens`` (no head consumes it today: off by default, it is a second
+        full-size write per tap).  bn[i] is indexed by STAGE i.  Every buffer is allocated on the launching stream, so forwards on
+        different streams (mvp/pipeline.py) share nothing but the weights and the tap-BN running statistics, ordered below."""
         images = images.to(self.device, torch.float32).contiguous()
         B = images.shape[0]
         outs = TapOutputs()
@@ -135,11 +139,16 @@ class ResNetEngine:
                 ws = torch.empty(ops.bn_tokens_workspace_bytes(B * HW, C) // 4 + 16, dtype=torch.float32, device=self.device)
                 stats = torch.empty(2 * C, dtype=torch.float32, device=self.device)
                 b = bn[i] if bn is not None else None
+                ordered = b is not None and bn_mode == 0
+                if ordered:
+                    self._tap_order.before(i)
                 ops.bn_tokens_to_nchw(xF, B, HW, C, HW, workspace=ws, stats=stats,
                                       gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                                       running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                                       nchw=nchw, tok=tok, ld_tok=C, col_off=0, mode=bn_mode,
                                       num_batches_tracked=b.get("num_batches_tracked") if b else None)
+                if ordered:
+                    self._tap_order.after(i)
                 outs.append(nchw)
                 outs.tokens.append(tok)
                 outs.dims.append((C, H, W))

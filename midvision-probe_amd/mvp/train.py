@@ -101,7 +101,7 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
         if not detach_model:
             extract_features(model, None, detach_model)  # raises: backbone fine-tuning is outside the frozen hot path
         # the frozen forward of batch t+1 is already in flight (side stream) while the probe step of batch t runs
-        for i, (batch, feats) in enumerate(pipelined_features(model, _device_batches(train_loader, dev))):
+        for i, (batch, feats) in enumerate(pipelined_features(model, _device_batches(train_loader, dev), probe=probe)):
             target = batch["depth"].to(dev, non_blocking=True).contiguous()
             loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, None, target, detach_model, scale_invariant, feats=feats)
             train_loss += loss.item()  # the reference syncs every step too (train_depth.py:143)

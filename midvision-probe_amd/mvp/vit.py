@@ -133,7 +133,8 @@ class ViTEngine:
         self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
         self._packs: Dict[Tuple[int, int, int, int, int], PackedFeatures] = {}
         self._slot_outs: Dict[tuple, dict] = {}  # output maps of pipelined forwards, owned by the slot
-        self._tap_events: Dict[int, torch.cuda.Event] = {}  # tap index -> "running statistics updated" of the latest pipelined forward
+        self._tap_order = pipeline.UpdateOrder()  # tap-BN running statistics are updated in batch order across streams
+        pipeline.publish()  # the split weights are read by forwards on any stream
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, B: int, gh: int, gw: int) -> dict:
@@ -175,6 +176,7 @@ class ViTEngine:
             assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
             pe = torch.cat((self.pos_embed[0, :1], grid.permute(0, 2, 3, 1).reshape(-1, self.C)), dim=0).contiguous()
         self._pos[key] = pe
+        pipeline.publish()
         return pe
 
     def set_pos_embed(self, pos_embed: torch.Tensor) -> None:
@@ -254,18 +256,14 @@ class ViTEngine:
 
         # Train-mode tap BN updates its running statistics in place.  With several forwards in flight on different streams those
         # read-modify-writes must happen in batch order: tap j waits for tap j of the previous forward (an event per tap).
-        order_taps = bn is not None and bn_mode == 0 and (pipeline.pipelined() or bool(self._tap_events))
+        order_taps = bn is not None and bn_mode == 0
 
         def tap(j):
             if order_taps:
-                prev = self._tap_events.pop(j, None)
-                if prev is not None:
-                    torch.cuda.current_stream().wait_event(prev)
+                self._tap_order.before(j)
             tap_kernel(j)
-            if order_taps and pipeline.pipelined():
-                ev = torch.cuda.Event()
-                ev.record()
-                self._tap_events[j] = ev
+            if order_taps:
+                self._tap_order.after(j)
 
         def tap_kernel(j):
             if slot_out:

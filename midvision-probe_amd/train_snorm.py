@@ -45,7 +45,7 @@ def main(argv):
         tot = 0.0
         if world > 1:
             loader.sampler.set_epoch(ep)
-        for batch, feats in pipelined_features(model, DevicePrefetcher(loader, dev)):  # forward of the next batch already in flight
+        for batch, feats in pipelined_features(model, DevicePrefetcher(loader, dev), probe=probe):  # forward of the next batch already in flight
             target = batch["snorm"]
             mask = batch["depth"] > 0                               # train_snorm.py:95
             tot += train_snorm_step(model, probe, opt, sched, None, target, mask, feats=feats).item()

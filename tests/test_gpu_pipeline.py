@@ -115,16 +115,30 @@ def test_pipeline_matches_plain_step_and_mixes_with_direct_calls():
     assert all(torch.isfinite(t).all() for t in f)
 
 
-def test_backbones_without_slots_run_inline():
-    """ResNet engines keep no per-slot buffers: the pipeline degrades to the caller's stream (depth 1) instead of racing."""
+def test_resnet_forwards_in_flight_match_serial():
+    """ResNet engines allocate per forward on the launching stream; shared state = weights + tap-BN running statistics (ordered
+    by events).  Three forwards in flight give the features and running statistics of three serial calls, bit for bit."""
     from evals.models.dino_res50 import DINO_RESNET
     from mvp.pipeline import FeaturePipeline
 
     dev = torch.device("cuda:0")
-    model = DINO_RESNET(return_layers=[1, 2, 3, 4], return_multilayer=True, add_norm=True, fixed_size=96).to(dev)
-    pipe = FeaturePipeline(model, 2)
-    assert pipe.depth == 1 and pipe.streams == []
-    x = torch.randn(2, 3, 96, 96, device=dev)
-    pipe.submit(x)
-    a = pipe.next()
-    assert all(torch.isfinite(t).all() for t in a)
+    xs = [torch.randn(2, 3, 96, 96, generator=torch.Generator().manual_seed(40 + i)).to(dev) for i in range(3)]
+
+    def build():
+        return DINO_RESNET(return_layers=[1, 2, 3, 4], return_multilayer=True, add_norm=True, fixed_size=96, init_seed=5).to(dev)
+
+    m = build()
+    ref = [[t.clone() for t in m(x)] for x in xs]
+    ref_rm = [b.running_mean.clone() for b in m.batchnorms]
+    m = build()
+    pipe = FeaturePipeline(m, 3)
+    assert pipe.depth == 3
+    for x in xs:
+        pipe.submit(x)
+    got = [[t.clone() for t in pipe.next()] for _ in xs]
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    for a, b in zip((bn.running_mean for bn in m.batchnorms), ref_rm):
+        assert torch.equal(a, b)

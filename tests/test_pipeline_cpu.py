@@ -69,3 +69,18 @@ def test_default_depth_env(monkeypatch):
     assert pipeline.default_depth() == 1
     monkeypatch.setenv("MVP_INFLIGHT", "0")
     assert pipeline.default_depth() == 1
+
+
+def test_default_depth_by_probe(monkeypatch):
+    from mvp import pipeline
+
+    class P:
+        def __init__(self, name):
+            self.name = name
+
+    monkeypatch.delenv("MVP_INFLIGHT", raising=False)
+    assert pipeline.default_depth(P("bindepth_linear_k1")) == 2
+    assert pipeline.default_depth(P("bindepth_dpt_k3")) == 1
+    assert pipeline.default_depth(P("snorm_dpt_k3_UA")) == 1
+    monkeypatch.setenv("MVP_INFLIGHT", "3")
+    assert pipeline.default_depth(P("bindepth_dpt_k3")) == 3

@@ -8,7 +8,10 @@ set -eo pipefail
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-ARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 7 --warmup 3"
+# --inflight 1: one serial kernel chain, so a kernel's duration and counters are the kernel alone on the chip (what roofline.achieved
+# in bench.py is quoted on).  The default run keeps two forwards in flight (mvp/pipeline.py): its trace is collected separately below.
+ARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 7 --warmup 3 --inflight 1"
+PARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 8 --warmup 4 --no-serial-leg"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1
@@ -16,7 +19,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT \
   --output-format csv -d $OUT/${TAG}_pmc_sq -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/${TAG}_pmc_tcc -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_pmc_tcc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_pipelined_stats -- python3 $ROOT/bench.py $PARGS > $OUT/${TAG}_pipelined_stats.log 2>&1
 cd $ROOT
 python3 tools/make_profiles.py $TAG $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_tcc > $OUT/${TAG}_make_profiles.log 2>&1 || true
 mkdir -p $OUT/${TAG}_profiles && cp profiles/${TAG}_* $OUT/${TAG}_profiles/ 2>/dev/null || true
+cp $(find $OUT/${TAG}_pipelined_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_profiles/${TAG}_pipelined_kernel_stats.csv || true
+python3 tools/step_trace.py $(find $OUT/${TAG}_pipelined_stats -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_profiles/${TAG}_pipelined_step_trace.txt || true
 echo "profile passes done: $(ls $OUT | grep ${TAG}_ | wc -l) entries"
