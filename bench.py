@@ -284,6 +284,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    from mvp.pipeline import freeze_gc
+
+    freeze_gc()  # as the trainers do (mvp/train.py): no full-heap collector pause (75-110 ms) in the middle of a leg
     losses = []  # device scalars, reduced after the timed region (no accumulate kernel inside it, no host sync per step)
     run_steps(0, args.warmup, losses)
     barrier()

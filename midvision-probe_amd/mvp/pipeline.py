@@ -78,6 +78,16 @@ class UpdateOrder:
             self._events[key] = ev
 
 
+def freeze_gc() -> None:
+    """Move everything allocated so far (torch's modules: ~10^6 objects) into the collector's permanent generation.  A generation-2
+    collection otherwise walks all of it in the middle of the loop: a 75-110 ms host pause once per ~100 steps of this step, which
+    drains the device queue (tools/micro/leg_timeline.py: 100-step legs at 2.44 ms/step without the pause, 2.78-3.08 with it)."""
+    import gc
+
+    gc.collect()
+    gc.freeze()
+
+
 def default_depth(probe=None) -> int:
     """Forwards kept in flight by the trainers and bench.py.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).
     Otherwise 2, except under a DPT probe: measured on MI355X at B=16 (bench.py, img/s, 1 -> 2 in flight) the linear probe gains
@@ -87,6 +97,10 @@ def default_depth(probe=None) -> int:
     if env is not None:
         return max(1, int(env))
     if probe is not None and "_dpt_" in str(getattr(probe, "name", "")):
+        return 1
+    if os.environ.get("MVP_FORCE_DEVICE") is not None:
+        # several ranks rehearsing on ONE card (tests, bench.py over gloo): their 3 queues each oversubscribe the card's hardware
+        # queues and the processes get time-sliced (measured: 150 ms per step instead of 3)
         return 1
     return 2
 

@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import functional as MF
-from .pipeline import pipelined_features
+from .pipeline import freeze_gc, pipelined_features
 
 
 def extract_features(model, images, detach_model=True):
@@ -94,6 +94,7 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
     """Reference signature: train_depth.py:76-92.  Batches are dicts {"image", "depth"} (nyu.py:245-251)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     history = []
+    freeze_gc()  # no full-heap collector pause inside the loop
     for ep in range(n_epochs):
         if world_size > 1 and hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
             train_loader.sampler.set_epoch(ep)

@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from mvp import checkpoint, config  # noqa: E402
 from mvp import dist as mdist  # noqa: E402
 from mvp.optim import FlatAdamW  # noqa: E402
-from mvp.pipeline import pipelined_features  # noqa: E402
+from mvp.pipeline import freeze_gc, pipelined_features  # noqa: E402
 from mvp.train import train_snorm_step  # noqa: E402
 
 
@@ -41,6 +41,7 @@ def main(argv):
     opt = FlatAdamW([{"params": probe.parameters(), "lr": cfg["optimizer"]["probe_lr"]}], overlap_comm=world > 1)
     n_ep = cfg["optimizer"]["n_epochs"]
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, n_ep * nb, cfg["optimizer"]["warmup_epochs"] * nb))
+    freeze_gc()  # no full-heap collector pause inside the loop
     for ep in range(n_ep):
         tot = 0.0
         if world > 1:
