@@ -50,7 +50,7 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 2
+#define MVP_ABI_VERSION 3
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
 int mvp_sizeof(const char* struct_name); /* sizeof(<struct_name>) as compiled into the library, -1 if unknown: for bindings to self-check */
@@ -136,7 +136,16 @@ typedef struct {
   /* --- optional residual given as a bf16 pair (row stride ldr, elements), added like `residual`:
    * lets a frozen trunk keep block outputs only as pairs (ResNet identities, dino_res50.py:83-101). */
   const mvp_bf16* residual_hi; const mvp_bf16* residual_lo;
+  /* --- tile policy of the plain (non-conv, non-split-K) bf16x3 GEMMs:
+   * MVP_TILES_ALONE (0): the launch has the chip to itself (one serial kernel chain): tiles small enough that every CU holds
+   *   several workgroups (64x64 for the N = 768 projections at M ~ 3k: 600 tiles on 256 CUs);
+   * MVP_TILES_SHARED (1): other kernel chains run beside it on other streams (mvp/pipeline.py keeps >= 3 frozen forwards in
+   *   flight): 128x128 tiles everywhere.  They need 31 % less SIMD time per output (an LDS-DMA piece costs its SIMD ~5 MFMAs, and a
+   *   128x128 tile issues 6 MFMAs per piece against 3), and the CUs their coarse grid leaves idle are filled by the other chains. */
+  int tile_policy;
 } mvp_gemm_args;
+#define MVP_TILES_ALONE 0
+#define MVP_TILES_SHARED 1
 #define MVP_GEMM_STREAMK (-1)
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
 int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits);

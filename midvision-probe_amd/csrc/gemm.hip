@@ -662,6 +662,16 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   // overlap each other's load and MFMA phases better than a second stage would (two stages at BK = 64 cost the
   // residency and measured slower everywhere except the few-tile probe head).
   const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+  // Other kernel chains share the chip (mvp_hip.h, MVP_TILES_SHARED): the big tile's lower SIMD time per output wins once the CUs its
+  // coarse grid leaves idle are filled by someone else.  Measured (bench.py, B = 16, 224^2, img/s, 64x64-family rule -> 128x128 everywhere):
+  // one chain 5517 -> 4382, two chains in flight 6384 -> 6160, three 6609 -> 7228 (128x64 for N < 1024 instead: 7102).
+  // MVP_GEMM_BIG (diagnostic override): 1 / 2 force 128x128 / 128x64-below-1024 whatever the policy, 0 forces the ALONE rule.
+  static const int big_env = [] { const char* e = getenv("MVP_GEMM_BIG"); return e ? atoi(e) : -1; }();
+  const int big = big_env >= 0 ? big_env : (a->tile_policy == MVP_TILES_SHARED ? 1 : 0);
+  if (x3 && big && !(a->N <= 256 && a->K >= 2048)) {
+    if (a->N >= 1024 || big == 1) return launch_gemm<128, 128, 64, 3, 1, false, 8>(a, s);
+    return launch_gemm<128, 64, 64, 3, 1>(a, s);
+  }
   if (x3) {
     if (a->N <= 256 && a->K >= 2048) {  // probe head: few tiles, long K
       if (a->M >= 8192) return launch_gemm<128, 64, 64, 3, 1>(a, s);

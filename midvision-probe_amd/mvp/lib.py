@@ -52,7 +52,7 @@ class GemmArgs(C.Structure):
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
                 ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64),
-                ("residual_hi", _vp), ("residual_lo", _vp)]
+                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i)]
 
 
 class LayerNormArgs(C.Structure):

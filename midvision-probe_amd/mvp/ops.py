@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import lib
+from . import lib, pipeline
 from .lib import PREC_BF16, PREC_BF16X3
 
 Pair = Tuple[torch.Tensor, Optional[torch.Tensor]]
@@ -152,6 +152,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
         ldr if ldr is not None else N, ldo if ldo is not None else N, ldob if ldob is not None else N,
         act, precision, row_group, row_group_stride, row_group_off, res_row_mod)
     args.act_after_res = int(act_after_res)
+    args.tile_policy = pipeline.tile_policy()
     if out_mask is not None:
         args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
     if residual_pair is not None:

@@ -29,6 +29,8 @@ import torch
 
 _SLOT = 0  # slot of the forward being enqueued (host state; kernels are enqueued by one host thread)
 _PIPELINED = False
+_SHARED = False  # >= 3 forwards in flight: the GEMMs pick the tiles meant for a shared chip (mvp_hip.h, MVP_TILES_SHARED)
+SHARED_TILES_FROM = 3
 
 
 def current_slot() -> int:
@@ -40,15 +42,21 @@ def pipelined() -> bool:
     return _PIPELINED
 
 
+def tile_policy() -> int:
+    """mvp_gemm_args.tile_policy of a GEMM launched now: 1 (MVP_TILES_SHARED) inside a forward of a pipeline that keeps three or more
+    forwards in flight, else 0 (MVP_TILES_ALONE)."""
+    return 1 if _SHARED else 0
+
+
 @contextlib.contextmanager
-def _slot(i: int):
-    global _SLOT, _PIPELINED
-    prev = (_SLOT, _PIPELINED)
-    _SLOT, _PIPELINED = i, True
+def _slot(i: int, depth: int = 2):
+    global _SLOT, _PIPELINED, _SHARED
+    prev = (_SLOT, _PIPELINED, _SHARED)
+    _SLOT, _PIPELINED, _SHARED = i, True, depth >= SHARED_TILES_FROM
     try:
         yield
     finally:
-        _SLOT, _PIPELINED = prev
+        _SLOT, _PIPELINED, _SHARED = prev
 
 
 def publish() -> None:
@@ -90,19 +98,20 @@ def freeze_gc() -> None:
 
 def default_depth(probe=None) -> int:
     """Forwards kept in flight by the trainers and bench.py.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).
-    Otherwise 2, except under a DPT probe: measured on MI355X at B=16 (bench.py, img/s, 1 -> 2 in flight) the linear probe gains
-    5440-5510 -> 6330-6640 at 224^2 and 1041 -> 1062 at 480x640 (B=64: 7403 -> 7598), while the DPT probe step — 19 ms of
-    chip-filling convolutions per batch — loses 739-748 -> 699-723 to the forward running beside it."""
+    Otherwise 3, except under a DPT probe.  Measured on MI355X at B=16 (bench.py, img/s): linear probe at 224^2 — one chain
+    5440-5660, two 6380-6450, three 6610 with the same tiles and **7150-7230 with the shared-chip tiles** three or more chains
+    select (tile_policy), four 6210-6340, five 6820-6950, six 6210-7120 (GPU_MAX_HW_QUEUES 8 / 16 change nothing);
+    the DPT probe step — 19 ms of chip-filling convolutions per batch — loses 739-748 -> 699-723 to a forward running beside it."""
     env = os.environ.get("MVP_INFLIGHT")
     if env is not None:
         return max(1, int(env))
     if probe is not None and "_dpt_" in str(getattr(probe, "name", "")):
         return 1
     if os.environ.get("MVP_FORCE_DEVICE") is not None:
-        # several ranks rehearsing on ONE card (tests, bench.py over gloo): their 3 queues each oversubscribe the card's hardware
+        # several ranks rehearsing on ONE card (tests, bench.py over gloo): their queues oversubscribe the card's hardware
         # queues and the processes get time-sliced (measured: 150 ms per step instead of 3)
         return 1
-    return 2
+    return 3
 
 
 def _tensors(obj):
@@ -164,7 +173,7 @@ class FeaturePipeline:
         cur = torch.cuda.current_stream()
         # the batch is ready on the caller's stream, and the probe step that read this slot's buffers is already enqueued there
         s.wait_stream(cur)
-        with torch.cuda.stream(s), _slot(slot):
+        with torch.cuda.stream(s), _slot(slot, self.depth):
             feats = extract_features(self.model, images)
             done = torch.cuda.Event()
             done.record(s)
