@@ -303,7 +303,7 @@ def main():
     images_per_s = world * B * args.steps / dt
 
     # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
-    pipeline_info = {"inflight": pipe.depth,
+    pipeline_info = {"inflight": pipe.depth, "hipgraph_forward": pipe.graphs, "gemm_tiles": "shared-chip (128x128)" if pipe.depth >= 3 else "alone",
                      "what": "frozen forwards of upcoming batches run on side HIP streams under the probe step of the current batch; "
                              "every step still runs its own full forward + probe forward/backward/AdamW inside the timed region"}
     if pipe.depth > 1 and not args.no_serial_leg:

@@ -196,7 +196,7 @@ int mvp_cls_rows(const mvp_cls_rows_args*, void* stream);
  * token -> NCHW dense-map transpose.  Replaces nn.BatchNorm1d on x.permute(0,2,1)
  * (evals/models/dino.py:185-191) + tokens_to_output("dense") (evals/models/utils.py:111-114).
  *   stats pass : per-channel mean / biased var over all B*N rows -> stats[2*C] (mean, var),
- *                running stats updated with momentum & unbiased var when running_* != NULL;
+ *                running stats updated with momentum & unbiased var when running_* != NULL (unless defer_running);
  *   apply pass : y = (x - mean) * rsqrt(var + eps) * gamma + beta, spatial tokens only
  *                (the last hw tokens of each image), written as
  *                  nchw   [B, C, h, w] fp32          (the reference's return value)
@@ -222,9 +222,24 @@ typedef struct {
   float* cls_out;       /* [B, C] fp32 or NULL: the normalised FIRST token of each image (the CLS token that
                            tokens_to_output(output="cls" / "dense-cls") returns, utils.py:105-124); needs N > hw */
   int64_t* num_batches_tracked; /* or NULL: BatchNorm's step counter, incremented in train mode (mode 0) by the statistics kernel */
+  int defer_running;    /* 1 (mode 0 only): leave running_mean / running_var / num_batches_tracked untouched and write the unbiased
+                           variance to stats[2*C .. 3*C) (stats then holds 3*C floats); mvp_bn_running_update applies the update later.
+                           For forwards that run concurrently on several streams (mvp/pipeline.py): the running statistics are the only
+                           state a frozen forward mutates, and their momentum updates must happen in batch order.                     */
 } mvp_bn_tokens_args;
 int64_t mvp_bn_tokens_workspace_bytes(int M, int C);
 int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args*, void* stream);
+
+/* The deferred half of nn.BatchNorm's train-mode bookkeeping (torch/nn/modules/batchnorm.py; dino.py:185-191 keeps the tap BNs in
+ * train mode): running = (1 - momentum) * running + momentum * batch statistic (unbiased variance), num_batches_tracked += 1.
+ * Same arithmetic, bit for bit, as the in-kernel update of mvp_bn_tokens_to_nchw_fwd with defer_running = 0. */
+typedef struct {
+  const float* stats;   /* [3*C]: mean, biased var, unbiased var — as written with defer_running = 1 */
+  float* running_mean; float* running_var;  /* [C] */
+  int64_t* num_batches_tracked;             /* or NULL */
+  int C; float momentum;
+} mvp_bn_running_update_args;
+int mvp_bn_running_update(const mvp_bn_running_update_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * NCHW fp32 feature maps -> token-major bf16 pair (+ transposed copy).  Fallback packer

@@ -664,7 +664,8 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   const long t128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
   // Other kernel chains share the chip (mvp_hip.h, MVP_TILES_SHARED): the big tile's lower SIMD time per output wins once the CUs its
   // coarse grid leaves idle are filled by someone else.  Measured (bench.py, B = 16, 224^2, img/s, 64x64-family rule -> 128x128 everywhere):
-  // one chain 5517 -> 4382, two chains in flight 6384 -> 6160, three 6609 -> 7228 (128x64 for N < 1024 instead: 7102).
+  // one chain 5517 -> 4382, two chains in flight 6384 -> 6160, three 6609 -> 7228 (128x64 for N < 1024 instead: 7102; 256x128 with
+  // 8 waves for N >= 1024: 6504, for every GEMM: 6210 — one 96 KB workgroup per CU leaves no room for a second chain's workgroup).
   // MVP_GEMM_BIG (diagnostic override): 1 / 2 force 128x128 / 128x64-below-1024 whatever the policy, 0 forces the ALONE rule.
   static const int big_env = [] { const char* e = getenv("MVP_GEMM_BIG"); return e ? atoi(e) : -1; }();
   const int big = big_env >= 0 ? big_env : (a->tile_policy == MVP_TILES_SHARED ? 1 : 0);

@@ -31,7 +31,7 @@ extern "C" int mvp_sizeof(const char* name) {
   MVP_SZ(mvp_depth_predict_args) MVP_SZ(mvp_depth_loss_args) MVP_SZ(mvp_angular_loss_args) MVP_SZ(mvp_colsum_args) MVP_SZ(mvp_adamw_args)
   MVP_SZ(mvp_corr_argmax_args) MVP_SZ(mvp_conv_weight_pack_args) MVP_SZ(mvp_upsample_cl_args) MVP_SZ(mvp_gemm_tn_args)
   MVP_SZ(mvp_depth_metrics_args) MVP_SZ(mvp_snorm_metrics_args) MVP_SZ(mvp_linear_bins_args) MVP_SZ(mvp_im2col_args)
-  MVP_SZ(mvp_maxpool_cl_args) MVP_SZ(mvp_mask_split_args) MVP_SZ(mvp_metrics_breakdown_args) MVP_SZ(mvp_argmax_2d_args) MVP_SZ(mvp_scale_shift_args) MVP_SZ(mvp_stem_args)
+  MVP_SZ(mvp_maxpool_cl_args) MVP_SZ(mvp_mask_split_args) MVP_SZ(mvp_metrics_breakdown_args) MVP_SZ(mvp_argmax_2d_args) MVP_SZ(mvp_scale_shift_args) MVP_SZ(mvp_stem_args) MVP_SZ(mvp_bn_running_update_args)
 #undef MVP_SZ
   return -1;
 }

@@ -117,6 +117,12 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // unbiased var) and the affine scale/shift used by the apply pass.
 constexpr int BN_FC = 16, BN_FG = 64;
 
+// The momentum update of a running statistic, written with explicit roundings (no FMA contraction) so that the in-kernel form and the
+// deferred form (bn_running_update_kernel) give the same bits: (1 - m) * old + m * val, every operation rounded as torch's CPU kernel does.
+__device__ __forceinline__ float bn_running(float old, float val, float momentum) {
+  return __fadd_rn(__fmul_rn(1.f - momentum, old), __fmul_rn(momentum, val));
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
                                                            float* __restrict__ ss, int M, int nslab, int rb) {
   __shared__ double red[BN_FG][BN_FC][2];
@@ -161,16 +167,26 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_a
   const double var = m2 / n;
   p.stats[c] = (float)mean;
   p.stats[p.C + c] = (float)var;
-  if (p.running_mean) {
-    const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
-    p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
-    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unb;
+  const double unb = (n > 1.0) ? m2 / (n - 1.0) : var;
+  if (p.defer_running) {
+    p.stats[2 * p.C + c] = (float)unb;  // mvp_bn_running_update applies it later, in batch order
+  } else if (p.running_mean) {
+    p.running_mean[c] = bn_running(p.running_mean[c], (float)mean, p.momentum);
+    p.running_var[c] = bn_running(p.running_var[c], (float)unb, p.momentum);
   }
   const float rstd = rsqrtf((float)var + p.eps);
   const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
   ss[c] = rstd * g;
   ss[p.C + c] = b - (float)mean * rstd * g;
-  if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;  // nn.BatchNorm train-mode bookkeeping, no extra launch
+  if (c == 0 && p.num_batches_tracked && !p.defer_running) *p.num_batches_tracked += 1;  // nn.BatchNorm train-mode bookkeeping, no extra launch
+}
+
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const mvp_bn_running_update_args p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+  if (c >= p.C) return;
+  p.running_mean[c] = bn_running(p.running_mean[c], p.stats[c], p.momentum);
+  p.running_var[c] = bn_running(p.running_var[c], p.stats[2 * p.C + c], p.momentum);
 }
 
 // eval (running stats) / identity modes: scale & shift without a statistics pass.
@@ -321,6 +337,7 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   const int M = a->B * a->N;
   if (a->workspace_bytes < mvp_bn_tokens_workspace_bytes(M, a->C)) return MVP_EINVAL;
   if (a->mode == 0 && !a->stats) return MVP_EINVAL;
+  if (a->defer_running && a->mode != 0) return MVP_EINVAL;
   if (a->mode == 1 && (!a->running_mean || !a->running_var)) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int rb = bn_slab_rows(M);
@@ -338,6 +355,13 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
     const int ptiles = (a->hw + 31) / 32;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(a->B * ptiles, (a->C + 63) / 64), dim3(256), 0, s, *a, ss);
   }
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_bn_running_update(const mvp_bn_running_update_args* a, void* stream) {
+  if (!a || !a->stats || !a->running_mean || !a->running_var || a->C <= 0) return MVP_EINVAL;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((a->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

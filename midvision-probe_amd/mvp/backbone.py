@@ -162,7 +162,8 @@ class ViTBackbone(nn.Module):
     ln_eps = 1e-6
     pos_embed_mode = "dino"
     tap_input_of_block = False
-    supports_pipelining = True  # the engine keeps its buffers per pipeline slot and orders tap-BN updates (mvp/pipeline.py)
+    supports_pipelining = True  # per-slot buffers, tap-BN running-statistics updates deferred to the consumer (mvp/pipeline.py)
+    graph_safe = True  # a pipelined forward launches only this library's kernels on fixed buffers: it can be captured in a hipGraph
 
     def _setup_taps(self, feat_dim, layer, return_multilayer, add_norm, num_layers):
         multilayers = multilayer_indices(num_layers)

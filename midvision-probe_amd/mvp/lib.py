@@ -74,7 +74,12 @@ class BnTokensArgs(C.Structure):
                 ("nchw", _vp), ("tok_hi", _vp), ("tok_lo", _vp), ("ld_tok", _i), ("col_off", _i),
                 ("tokT_hi", _vp), ("tokT_lo", _vp), ("ldT", _i),
                 ("workspace", _vp), ("workspace_bytes", _i64),
-                ("B", _i), ("N", _i), ("C", _i), ("hw", _i), ("eps", _f), ("momentum", _f), ("mode", _i), ("cls_out", _vp), ("num_batches_tracked", _vp)]
+                ("B", _i), ("N", _i), ("C", _i), ("hw", _i), ("eps", _f), ("momentum", _f), ("mode", _i), ("cls_out", _vp), ("num_batches_tracked", _vp),
+                ("defer_running", _i)]
+
+
+class BnRunningUpdateArgs(C.Structure):
+    _fields_ = [("stats", _vp), ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp), ("C", _i), ("momentum", _f)]
 
 
 class PackNchwArgs(C.Structure):
@@ -199,6 +204,7 @@ SYMBOLS = {
     "mvp_cls_rows": ClsRowsArgs,
     "mvp_bn_tokens_workspace_bytes": None,
     "mvp_bn_tokens_to_nchw_fwd": BnTokensArgs,
+    "mvp_bn_running_update": BnRunningUpdateArgs,
     "mvp_pack_nchw_tokens": PackNchwArgs,
     "mvp_resize_fwd": ResizeArgs,
     "mvp_resize_bwd": ResizeArgs,

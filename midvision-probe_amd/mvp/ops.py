@@ -209,17 +209,25 @@ def bn_tokens_workspace_bytes(M: int, Cdim: int) -> int:
 
 def bn_tokens_to_nchw(x, B, N, Cdim, hw, *, workspace, stats=None, gamma=None, beta=None, running_mean=None, running_var=None,
                       nchw=None, tok: Optional[Pair] = None, ld_tok=0, col_off=0, tokT: Optional[Pair] = None, ldT=0,
-                      eps=1e-5, momentum=0.1, mode=0, cls_out=None, num_batches_tracked=None) -> None:
+                      eps=1e-5, momentum=0.1, mode=0, cls_out=None, num_batches_tracked=None, defer_running=False) -> None:
+    """``defer_running`` (mode 0): the running statistics and the step counter are left alone, ``stats`` ([3*C]) also receives the
+    unbiased variance, and ``bn_running_update`` applies the momentum update later (forwards in flight on several streams)."""
     t_hi, t_lo = tok if tok is not None else (None, None)
     tt_hi, tt_lo = tokT if tokT is not None else (None, None)
     a = lib.BnTokensArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(running_mean), lib.ptr(running_var), lib.ptr(stats),
                          lib.ptr(nchw), lib.ptr(t_hi), lib.ptr(t_lo), ld_tok, col_off, lib.ptr(tt_hi), lib.ptr(tt_lo), ldT,
                          lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode, lib.ptr(cls_out),
-                         lib.ptr(num_batches_tracked) if mode == 0 else None)
+                         lib.ptr(num_batches_tracked) if mode == 0 else None, int(bool(defer_running) and mode == 0))
     # algorithmic HBM bytes: x read twice in train mode (statistics, apply), NCHW fp32 + token-major pair written
     M = B * N
     nb = M * Cdim * 4 * (2 if mode == 0 else 1) + B * hw * Cdim * ((4 if nchw is not None else 0) + (4 if tok is not None and tok[1] is not None else (2 if tok is not None else 0)))
     _traced("hbm", "bn_tokens (partial+finalize+apply)", 0, float(nb), lambda: lib.call("mvp_bn_tokens_to_nchw_fwd", a))
+
+
+def bn_running_update(stats, running_mean, running_var, num_batches_tracked, Cdim, momentum=0.1) -> None:
+    """The deferred running-statistics update of a ``bn_tokens_to_nchw(..., defer_running=True)`` call (same bits as the fused form)."""
+    lib.call("mvp_bn_running_update", lib.BnRunningUpdateArgs(lib.ptr(stats), lib.ptr(running_mean), lib.ptr(running_var),
+                                                               lib.ptr(num_batches_tracked), Cdim, momentum))
 
 
 def pack_nchw_tokens(nchw: torch.Tensor, B: int, Cdim: int, hw: int, *, tok: Optional[Pair] = None, ld_tok=0, col_off=0,

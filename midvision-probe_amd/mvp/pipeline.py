@@ -67,23 +67,20 @@ def publish() -> None:
         torch.cuda.synchronize()
 
 
-class UpdateOrder:
-    """Keeps in-place updates of state shared by all forwards (the tap-BN running statistics, updated by every train-mode forward)
-    in batch order when forwards run on different streams: update ``key`` of forward t+1 waits for update ``key`` of forward t."""
+_DEFERRED = []  # state updates registered by the forward being enqueued, applied by the consumer in batch order
 
-    def __init__(self):
-        self._events = {}
 
-    def before(self, key) -> None:
-        prev = self._events.pop(key, None)
-        if prev is not None:
-            torch.cuda.current_stream().wait_event(prev)
+def defer(fn) -> None:
+    """Register an update of state shared by all forwards (the tap-BN running statistics and step counter: the only state a frozen
+    forward mutates).  A pipelined forward must not apply it itself — forwards on different streams finish in any order — so
+    ``FeaturePipeline.next()`` runs it on the trainer's stream when the batch is handed over: batch order, no cross-stream event."""
+    _DEFERRED.append(fn)
 
-    def after(self, key) -> None:
-        if _PIPELINED:  # a forward on the trainer's own stream is ordered by the stream itself
-            ev = torch.cuda.Event()
-            ev.record()
-            self._events[key] = ev
+
+def _take_deferred():
+    global _DEFERRED
+    out, _DEFERRED = _DEFERRED, []
+    return out
 
 
 def freeze_gc() -> None:
@@ -128,10 +125,16 @@ def _tensors(obj):
 
 class FeaturePipeline:
     """``submit(images)`` enqueues ``model(images)`` on a side stream; ``next()`` returns the oldest submitted features on the
-    caller's current stream (event wait, no host sync).  ``depth`` = forwards in flight; backbones whose engine does not keep
-    per-slot buffers (``supports_pipelining`` False) run inline on the caller's stream, as does depth 1."""
+    caller's current stream (event wait, no host sync) after applying the forward's deferred state updates.  ``depth`` = forwards
+    in flight; backbones without ``supports_pipelining`` run inline on the caller's stream, as does depth 1.
 
-    def __init__(self, model, depth: int = None, run_ahead: int = None):
+    ``graphs`` (default MVP_PIPELINE_GRAPHS != "0"): a ``graph_safe`` backbone's forward is captured once per (slot, input shape) in a
+    hipGraph and replayed — one launch call instead of ~100, 1.4 ms of host time per step down to 0.4, so a busy host (data loading,
+    logging) no longer starves the device.  The first forward of every slot runs eagerly (it allocates the slot's buffers and builds
+    lazily cached operands) and is then captured; later ones replay; the input batch is copied into the graph's static buffer.
+    A graph is tied to the engine it was captured from (rebuilt weights invalidate it: new key, new capture)."""
+
+    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None):
         """``run_ahead``: the host may be at most this many forwards ahead of the device (MVP_RUN_AHEAD, default 8; 0 = unbounded).
         The reference's loop syncs every step (``loss.item()``, train_depth.py:143); a loop that never syncs would otherwise queue
         hundreds of launches (and keep their argument buffers alive).  Throughput-neutral on MI355X (tools/micro/pipeline_probe.py,
@@ -148,24 +151,66 @@ class FeaturePipeline:
         self._n = 0
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
         self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
+        if graphs is None:
+            graphs = os.environ.get("MVP_PIPELINE_GRAPHS", "1") != "0"
+        self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
+        self._graphs = {}  # (slot, shape, dtype, training, engine id) -> dict(calls, graph, static_in, feats, deferred)
 
     def __len__(self) -> int:
         return len(self._queue)
 
+    # ------------------------------------------------------------------ one forward on a slot's stream
+    def _eager(self, slot: int, images: torch.Tensor):
+        with _slot(slot, self.depth):
+            _take_deferred()
+            feats = _extract(self.model, images)
+            return feats, _take_deferred()
+
+    def _forward(self, slot: int, s, images: torch.Tensor):
+        """Runs on stream ``s`` (current).  Returns (features, deferred updates)."""
+        if not self.graphs:
+            return self._eager(slot, images)
+        eng = self.model.engine() if hasattr(self.model, "engine") else None
+        key = (slot, tuple(images.shape), images.dtype, bool(self.model.training), id(eng))
+        ent = self._graphs.get(key)
+        if ent is None:
+            for k in [k for k in self._graphs if k[0] == slot]:  # one shape per slot: a new one replaces the old graph
+                del self._graphs[k]
+            ent = self._graphs[key] = dict(calls=0, graph=None)
+        ent["calls"] += 1
+        if ent["graph"] is None:
+            # First forward of this slot / shape: run it eagerly (it allocates the slot's buffers and builds lazily cached operands —
+            # none of that may happen inside a capture), then capture the very same call for all later batches.  Capturing launches
+            # nothing, so this batch's features are the eager ones; the capture's one-time cost (a device sync) lands here, in the
+            # slot's first call, not in the middle of the run.
+            out = self._eager(slot, images)
+            from .vit import lookup_pack
+
+            static_in = torch.empty_like(images)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                feats, deferred = self._eager(slot, static_in)
+            ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred,
+                       pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None)
+            return out
+        ent["static_in"].copy_(images, non_blocking=True)
+        ent["graph"].replay()
+        if ent["pack"] is not None:
+            ent["pack"].generation += 1  # the host code that counts rewrites of the packing does not run on a replay
+        return ent["feats"], ent["deferred"]
+
     def submit(self, images: torch.Tensor) -> None:
         if len(self._queue) >= self.depth:
             raise RuntimeError(f"{self.depth} forwards already in flight: call next() first")
-        from .train import extract_features
-
         if self.run_ahead > 0 and len(self._issued) >= self.run_ahead:
             self._issued.popleft().synchronize()  # host waits for the forward issued ``run_ahead`` submissions ago
         if self.depth == 1:
-            feats = extract_features(self.model, images)
+            feats = _extract(self.model, images)
             if self.run_ahead > 0 and images.is_cuda:
                 ev = torch.cuda.Event()
                 ev.record()
                 self._issued.append(ev)
-            self._queue.append((feats, None))
+            self._queue.append((feats, None, ()))
             return
         slot = self._n % self.depth
         self._n += 1
@@ -173,28 +218,36 @@ class FeaturePipeline:
         cur = torch.cuda.current_stream()
         # the batch is ready on the caller's stream, and the probe step that read this slot's buffers is already enqueued there
         s.wait_stream(cur)
-        with torch.cuda.stream(s), _slot(slot, self.depth):
-            feats = extract_features(self.model, images)
+        with torch.cuda.stream(s):
+            feats, deferred = self._forward(slot, s, images)
             done = torch.cuda.Event()
             done.record(s)
         if self.run_ahead > 0:
             self._issued.append(done)
         if images.is_cuda:
             images.record_stream(s)  # allocated on the caller's stream, read on the side stream
-        self._queue.append((feats, done))
+        self._queue.append((feats, done, deferred))
 
     def next(self):
-        feats, done = self._queue.popleft()
+        feats, done, deferred = self._queue.popleft()
         if done is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(done)
             for t in _tensors(feats):
                 t.record_stream(cur)  # allocated on the side stream, read (and later freed) under the caller's stream
+            for fn in deferred:  # tap-BN running statistics: applied here, on the caller's stream, in batch order
+                fn()
         return feats
 
     def drain(self) -> None:
         while self._queue:
             self.next()
+
+
+def _extract(model, images):
+    from .train import extract_features
+
+    return extract_features(model, images)
 
 
 def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None, probe=None) -> Iterator[Tuple[object, object]]:

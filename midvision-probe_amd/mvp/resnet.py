@@ -62,7 +62,6 @@ class ResNetEngine:
                 stage.append(blk)
             self.blocks.append(stage)
         self.stage_channels = [self.c0] + [st[-1]["cout"] for st in self.blocks]
-        self._tap_order = pipeline.UpdateOrder()  # tap-BN running statistics are updated in batch order across streams
         pipeline.publish()  # the folded / split weights are read by forwards on any stream
 
     # ------------------------------------------------------------------ stages (x = (fp32, pair), H, W)
@@ -119,7 +118,7 @@ class ResNetEngine:
         indices in ``multilayers`` (0 = stem+maxpool, 1..4 = layer1..4); ``outs.tokens[j]`` holds the
         channels-last bf16 pair of tap j when ``want_tokens`` (no head consumes it today: off by default, it is a second
         full-size write per tap).  bn[i] is indexed by STAGE i.  Every buffer is allocated on the launching stream, so forwards on
-        different streams (mvp/pipeline.py) share nothing but the weights and the tap-BN running statistics, ordered below."""
+        different streams (mvp/pipeline.py) share nothing but the weights and the tap-BN running statistics (deferred to the consumer)."""
         images = images.to(self.device, torch.float32).contiguous()
         B = images.shape[0]
         outs = TapOutputs()
@@ -137,18 +136,17 @@ class ResNetEngine:
                 nchw = torch.empty(B, C, H, W, dtype=torch.float32, device=self.device)
                 tok = ops.empty_pair((B * HW, C), self.pr, self.device) if want_tokens else None
                 ws = torch.empty(ops.bn_tokens_workspace_bytes(B * HW, C) // 4 + 16, dtype=torch.float32, device=self.device)
-                stats = torch.empty(2 * C, dtype=torch.float32, device=self.device)
+                stats = torch.empty(3 * C, dtype=torch.float32, device=self.device)
                 b = bn[i] if bn is not None else None
-                ordered = b is not None and bn_mode == 0
-                if ordered:
-                    self._tap_order.before(i)
+                # the running-statistics update of a forward in flight on a side stream is applied by the consumer, in batch order
+                defer = b is not None and bn_mode == 0 and pipeline.pipelined()
                 ops.bn_tokens_to_nchw(xF, B, HW, C, HW, workspace=ws, stats=stats,
                                       gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                                       running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                                       nchw=nchw, tok=tok, ld_tok=C, col_off=0, mode=bn_mode,
-                                      num_batches_tracked=b.get("num_batches_tracked") if b else None)
-                if ordered:
-                    self._tap_order.after(i)
+                                      num_batches_tracked=b.get("num_batches_tracked") if b else None, defer_running=defer)
+                if defer and b.get("running_mean") is not None:
+                    pipeline.defer(lambda st=stats, b=b, C=C: ops.bn_running_update(st, b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C))
                 outs.append(nchw)
                 outs.tokens.append(tok)
                 outs.dims.append((C, H, W))

@@ -58,7 +58,7 @@ class PackedFeatures:
 
 
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
-_PACK_REGISTRY_MAX = 4
+_PACK_REGISTRY_MAX = 16
 
 
 def _ver(t: torch.Tensor) -> int:
@@ -133,7 +133,6 @@ class ViTEngine:
         self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
         self._packs: Dict[Tuple[int, int, int, int, int], PackedFeatures] = {}
         self._slot_outs: Dict[tuple, dict] = {}  # output maps of pipelined forwards, owned by the slot
-        self._tap_order = pipeline.UpdateOrder()  # tap-BN running statistics are updated in batch order across streams
         pipeline.publish()  # the split weights are read by forwards on any stream
 
     # ------------------------------------------------------------------ helpers
@@ -245,27 +244,21 @@ class ViTEngine:
             okey = (B, gh, gw, tuple(layers), bool(want_cls), pipeline.current_slot())
             slot_out = self._slot_outs.get(okey)
             if slot_out is None:
-                slot_out = dict(stats=torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device),
+                slot_out = dict(stats=torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device),
                                 nchw=[torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device) for _ in layers],
                                 cls=[torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None for _ in layers])
                 self._slot_outs = {k: v for k, v in self._slot_outs.items() if k[:5] == okey[:5]}
                 self._slot_outs[okey] = slot_out
-        stats = slot_out["stats"] if slot_out else torch.empty(len(layers), 2 * C, dtype=torch.float32, device=self.device)
+        stats = slot_out["stats"] if slot_out else torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device)
 
         outs.cls = []
 
-        # Train-mode tap BN updates its running statistics in place.  With several forwards in flight on different streams those
-        # read-modify-writes must happen in batch order: tap j waits for tap j of the previous forward (an event per tap).
-        order_taps = bn is not None and bn_mode == 0
+        # Train-mode tap BN updates its running statistics in place: the only state a frozen forward mutates.  Forwards in flight on
+        # different streams finish in any order, so a pipelined forward leaves that update to the consumer (pipeline.defer), which
+        # applies it on the trainer's stream in batch order — same arithmetic, same bits (mvp_bn_running_update).
+        defer = bn is not None and bn_mode == 0 and pipeline.pipelined()
 
         def tap(j):
-            if order_taps:
-                self._tap_order.before(j)
-            tap_kernel(j)
-            if order_taps:
-                self._tap_order.after(j)
-
-        def tap_kernel(j):
             if slot_out:
                 nchw, cls = slot_out["nchw"][j], slot_out["cls"][j]
             else:
@@ -279,7 +272,10 @@ class ViTEngine:
                 gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                 running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                 nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
-                mode=bn_mode, cls_out=cls, num_batches_tracked=b.get("num_batches_tracked") if b else None)
+                mode=bn_mode, cls_out=cls, num_batches_tracked=b.get("num_batches_tracked") if b else None, defer_running=defer)
+            if defer and b is not None and b.get("running_mean") is not None:
+                st = stats[j]
+                pipeline.defer(lambda st=st, b=b: ops.bn_running_update(st, b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C))
             outs.append(nchw)
 
         last = max(layers)

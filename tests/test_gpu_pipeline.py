@@ -38,27 +38,38 @@ def _batches(dev, n, B=4, hw=(64, 80)):
     return out
 
 
-def _run(depth, probe_kind="linear", n=7):
+def _run(depth, probe_kind="linear", n=7, graphs=False):
     from evals.utils.losses import DepthLoss
-    from mvp.pipeline import pipelined_features
+    from mvp.pipeline import FeaturePipeline
     from mvp.train import train_depth_step
 
     dev = torch.device("cuda:0")
     model, probe, opt, sched = _build(dev, probe_kind)
     loss_fn = DepthLoss()
     losses = []
-    for batch, feats in pipelined_features(model, _batches(dev, n), depth=depth):
-        losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, batch["depth"].clone(), feats=feats))
+    pipe = FeaturePipeline(model, depth, graphs=graphs)
+    assert pipe.graphs == (graphs and depth > 1)
+    bs = _batches(dev, n)
+    nxt = 0
+    for i in range(n):
+        while len(pipe) < pipe.depth and nxt < n:
+            pipe.submit(bs[nxt]["image"])
+            nxt += 1
+        losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, bs[i]["depth"].clone(), feats=pipe.next()))
+    if graphs:  # every slot went through its eager call, its capture and at least one replay
+        assert len(pipe._graphs) == depth and all(e["graph"] is not None and e["calls"] >= 2 for e in pipe._graphs.values())
     torch.cuda.synchronize()
     bn = [torch.cat([b.running_mean, b.running_var]).cpu().numpy() for b in model.batchnorms]
     nbt = [int(b.num_batches_tracked) for b in model.batchnorms]
     return (torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(), opt.exp_avg_sq.cpu().numpy().copy(), bn, nbt)
 
 
-@pytest.mark.parametrize("depth", [2, 3])
-def test_pipelined_training_is_bit_identical_to_serial(depth):
+@pytest.mark.parametrize("depth,graphs", [(2, False), (3, False), (2, True), (3, True)])
+def test_pipelined_training_is_bit_identical_to_serial(depth, graphs):
+    """depth 3 also switches the backbone GEMMs to the shared-chip tiles (tile_policy): still the same bits.  graphs: every slot's
+    forward replays a captured hipGraph from its third call on; the tap-BN running statistics are applied by the consumer."""
     ref = _run(1)
-    got = _run(depth)
+    got = _run(depth, graphs=graphs)
     assert np.isfinite(ref[0]).all() and ref[4] == [7] * 4
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
@@ -69,8 +80,8 @@ def test_pipelined_training_is_bit_identical_to_serial(depth):
 
 
 def test_pipelined_dpt_probe_is_bit_identical_to_serial():
-    ref = _run(1, "dpt", n=4)
-    got = _run(2, "dpt", n=4)
+    ref = _run(1, "dpt", n=5)
+    got = _run(2, "dpt", n=5, graphs=True)
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
 
@@ -91,7 +102,7 @@ def test_pipeline_matches_plain_step_and_mixes_with_direct_calls():
     ref_w = opt.flat_param.clone()
 
     model, probe, opt, sched = _build(dev)
-    pipe = FeaturePipeline(model, 2)
+    pipe = FeaturePipeline(model, 2, graphs=False)
     assert pipe.depth == 2
     got = []
     pipe.submit(bs[0]["image"])
