@@ -142,6 +142,9 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=None,
                     help="frozen-backbone forwards kept in flight on side HIP streams (mvp/pipeline.py); 1 = one serial kernel chain; "
                          "default: mvp.pipeline.default_depth(probe) = what the trainers use (2 under the linear probe, 1 under DPT)")
+    ap.add_argument("--tiles", default="auto", choices=["auto", "alone", "shared"],
+                    help="GEMM tile policy (mvp_gemm_args.tile_policy): auto = what the pipeline selects (shared-chip 128x128 tiles from 3 forwards in flight); "
+                         "'shared' with --inflight 1 runs the pipelined run's kernels as one serial chain (profiling)")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra inflight=1 leg reported as pipeline.serial (profiling runs)")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
@@ -200,7 +203,15 @@ def main():
         args.inflight = 1  # per-kernel counters: one kernel on the chip at a time
     pmc_live = None
     if not (args.no_live_pmc or args.no_roofline) and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
-        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe]
+        from mvp.pipeline import SHARED_TILES_FROM, default_depth
+
+        class _ProbeName:  # default_depth only looks at the probe's name
+            name = f"bindepth_{args.probe}_k"
+
+        eff_depth = args.inflight if args.inflight is not None else default_depth(_ProbeName)
+        # the counters are collected on a serial chain (one kernel on the chip at a time) of the SAME kernel instantiations the timed run launches
+        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe,
+              "--tiles", "shared" if (eff_depth >= SHARED_TILES_FROM or args.tiles == "shared") else "alone"]
         pmc_live = live_pmc(wl)  # before this process makes any GPU call
     from mvp import dist as mdist
 
@@ -261,9 +272,14 @@ def main():
 
     from mvp.pipeline import FeaturePipeline
 
-    from mvp.pipeline import default_depth
+    from mvp.pipeline import SHARED_TILES_FROM, default_depth, shared_tiles
 
     pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else default_depth(probe))
+    if args.tiles == "alone" and pipe.depth >= SHARED_TILES_FROM:
+        raise SystemExit("--tiles alone contradicts --inflight >= 3 (the pipeline selects the shared-chip tiles)")
+    # the tile policy of the timed run's backbone GEMMs; a serial chain (--inflight 1) can be forced to it for profiling
+    tiles_shared = pipe.depth >= SHARED_TILES_FROM or args.tiles == "shared"
+    force_shared = args.tiles == "shared"
 
     def run_steps(i0, n, out=None, pipe=pipe):
         """Steps i0 .. i0+n-1, every one the full train_depth.py:99-143 body.  Up to ``inflight`` frozen forwards are in flight on side
@@ -272,7 +288,11 @@ def main():
         nxt = i0
         for i in range(i0, i0 + n):
             while len(pipe) < pipe.depth and nxt < i0 + n:
-                pipe.submit(batches[nxt % n_distinct][0])
+                if pipe.depth == 1 and force_shared:  # (a pipelined forward selects its policy itself)
+                    with shared_tiles(True):
+                        pipe.submit(batches[nxt % n_distinct][0])
+                else:
+                    pipe.submit(batches[nxt % n_distinct][0])
                 nxt += 1
             loss = train_depth_step(model, probe, opt, sched, loss_fn, None, batches[i % n_distinct][1], feats=pipe.next())
             if out is not None:
@@ -382,8 +402,9 @@ def main():
         trace = []
         ops.set_trace(trace)
         nrep = 3
-        for i in range(nrep):
-            step(args.warmup + args.steps + i)
+        with shared_tiles(tiles_shared):  # the timed run's kernel instantiations, one at a time on one stream
+            for i in range(nrep):
+                step(args.warmup + args.steps + i)
         barrier()
         ops.set_trace(None)
     if not args.no_roofline and rank == 0:
@@ -421,7 +442,11 @@ def main():
             "kernel": name, "launches_per_step": cnt // nrep, "avg_launch_us": round(sec / cnt * 1e6, 2),
             "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
             "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop); HIP events on the launch stream, taken in 3 extra "
-                    "steps run as ONE serial chain (inflight 1) so a launch duration is the kernel alone on the chip, as in a rocprofv3 trace of --inflight 1",
+                    "steps that launch the timed run's kernel instantiations as ONE serial chain, so a launch duration is the kernel alone on the chip — "
+                    "what rocprofv3 reports for this command too (kernel tracing serialises dispatches across streams)",
+            "chip_level": {"alg_tflops": round(images_per_s / world * f_img / 1e12, 2), "frac": round(images_per_s / world * f_img / 1e12 / 2500.0, 4),
+                           "note": "whole-step algorithmic flops / measured step time of the timed run; with several forwards in flight the chains overlap, "
+                                   "so launches_per_step x avg_launch_us summed over all_kernels exceeds ms_per_step"},
             "all_kernels": {f"{k[0]}:{k[1]}": {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2),
                                                 "alg_tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in groups.items()},
             "whole_step_alg_tflops": round(images_per_s / world * f_img / 1e12, 2),

@@ -39,7 +39,7 @@ def _traced(kind: str, tile: str, precision: int, work: float, fn) -> None:
     _TRACE.append((kind, tile, precision, work, e0, e1))
 
 
-def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: int = 1) -> str:
+def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: int = 1, tile_policy: int = 0) -> str:
     """Mirror of the tile choice in csrc/gemm.hip -> template arguments BM,BN,BK,SPLIT,NSTAGE."""
     if splitk > 1:
         bn = 128 if N >= 1024 else 64
@@ -48,6 +48,8 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
     if precision == PREC_BF16X3:
         if N <= 256 and K >= 2048:
             return "128, 64, 64, 3, 1" if M >= 8192 else "64, 64, 64, 3, 2"
+        if tile_policy == 1:  # MVP_TILES_SHARED
+            return "128, 128, 64, 3, 1"
         if N >= 1024:
             return "128, 128, 64, 3, 1" if (t128 <= 512 or t128 >= 1536) else "64, 128, 64, 3, 1"
         t64 = ((M + 63) // 64) * ((N + 63) // 64)
@@ -175,7 +177,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     e0.record()
     lib.call("mvp_gemm_bias_act_res", args)
     e1.record()
-    _TRACE.append(("gemm", "streamk 128, 128, 64" if use_sk else gemm_tile(M, N, K, precision, S), precision, 2.0 * M * N * K, e0, e1))
+    _TRACE.append(("gemm", "streamk 128, 128, 64" if use_sk else gemm_tile(M, N, K, precision, S, args.tile_policy), precision, 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,

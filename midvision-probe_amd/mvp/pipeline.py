@@ -93,6 +93,19 @@ def freeze_gc() -> None:
     gc.freeze()
 
 
+@contextlib.contextmanager
+def shared_tiles(on: bool = True):
+    """Force the GEMM tile policy of launches made inside the block (measurement: the shared-chip tiles on a serial chain, so that a
+    profiler sees the kernels of a pipelined run one at a time)."""
+    global _SHARED
+    prev = _SHARED
+    _SHARED = bool(on)
+    try:
+        yield
+    finally:
+        _SHARED = prev
+
+
 def default_depth(probe=None) -> int:
     """Forwards kept in flight by the trainers and bench.py.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).
     Otherwise 3, except under a DPT probe.  Measured on MI355X at B=16 (bench.py, img/s): linear probe at 224^2 — one chain

@@ -8,9 +8,9 @@ set -eo pipefail
 TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-# --inflight 1: one serial kernel chain, so a kernel's duration and counters are the kernel alone on the chip (what roofline.achieved
-# in bench.py is quoted on).  The default run keeps two forwards in flight (mvp/pipeline.py): its trace is collected separately below.
-ARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 7 --warmup 3 --inflight 1"
+# --inflight 1 --tiles shared: the default run's kernel instantiations (shared-chip 128x128 GEMM tiles) as one serial chain, so a kernel's
+# duration and counters are the kernel alone on the chip (what roofline.achieved in bench.py is quoted on).  The default run keeps two forwards in flight (mvp/pipeline.py): its trace is collected separately below.
+ARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 7 --warmup 3 --inflight 1 --tiles shared"
 PARGS="--no-cpu-baseline --no-roofline --sustained-steps 0 --steps 8 --warmup 4 --no-serial-leg"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1
