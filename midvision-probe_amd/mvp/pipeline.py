@@ -187,9 +187,12 @@ class FeaturePipeline:
         key = (slot, tuple(images.shape), images.dtype, bool(self.model.training), id(eng))
         ent = self._graphs.get(key)
         if ent is None:
-            for k in [k for k in self._graphs if k[0] == slot]:  # one shape per slot: a new one replaces the old graph
+            mine = [k for k in self._graphs if k[0] == slot]
+            for k in mine[:-1] if len(mine) >= 2 else []:  # at most two shapes per slot (full batches + an epoch's ragged last one)
                 del self._graphs[k]
             ent = self._graphs[key] = dict(calls=0, graph=None)
+        else:
+            self._graphs[key] = self._graphs.pop(key)  # most recently used last
         ent["calls"] += 1
         if ent["graph"] is None:
             # First forward of this slot / shape: run it eagerly (it allocates the slot's buffers and builds lazily cached operands —
@@ -204,7 +207,9 @@ class FeaturePipeline:
             with torch.cuda.graph(g, stream=s):
                 feats, deferred = self._eager(slot, static_in)
             ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred,
-                       pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None)
+                       pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None,
+                       # the graph holds raw addresses of the slot's buffers and of the engine's operands: both stay alive with it
+                       keep=(eng, eng.slot_state(slot) if hasattr(eng, "slot_state") else None))
             return out
         ent["static_in"].copy_(images, non_blocking=True)
         ent["graph"].replay()

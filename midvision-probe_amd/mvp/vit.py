@@ -156,6 +156,13 @@ class ViTEngine:
             self._ws[key] = ws
         return ws
 
+    def slot_state(self, slot: int) -> list:
+        """Every buffer set this engine currently keeps for pipeline slot ``slot`` (activation workspaces, feature packings, output
+        maps).  A captured hipGraph of that slot's forward holds their raw addresses: the pipeline keeps this list alive with the
+        graph, because the engine itself drops the buffers of other resolutions when a new one arrives."""
+        return ([v for k, v in self._ws.items() if k[-1] == slot] + [v for k, v in self._packs.items() if k[-1] == slot]
+                + [v for k, v in self._slot_outs.items() if k[-1] == slot] + list(self._pos.values()))
+
     def pos_for(self, gh: int, gw: int, dim2: int, dim3: int) -> torch.Tensor:
         """Pos-embed for a gh x gw grid.  'dino': bicubic resize with the +0.1 scale nudge of
         ibot_transformers.py:311-336 (done once per resolution, cached; torch's bicubic on the

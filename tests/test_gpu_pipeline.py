@@ -79,6 +79,45 @@ def test_pipelined_training_is_bit_identical_to_serial(depth, graphs):
     assert got[4] == ref[4]
 
 
+def test_ragged_batches_and_graph_replay():
+    """An epoch's smaller last batch changes the forward's shape: the engine then drops its buffers of the other shape, while other
+    slots still hold captured graphs that address them.  The graphs keep their buffers alive; full-size batches afterwards replay the
+    old graphs.  Same bits as the serial loop throughout."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import FeaturePipeline
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    sizes = [4, 4, 4, 4, 2, 4, 4, 4, 2, 4, 4]
+
+    def batches():
+        out = []
+        for i, b in enumerate(sizes):
+            g = torch.Generator().manual_seed(900 + i)
+            out.append((torch.randn(b, 3, 64, 80, generator=g).to(dev), (torch.rand(b, 1, 64, 80, generator=g) * 9 + 0.05).to(dev)))
+        return out
+
+    def run(depth, graphs):
+        model, probe, opt, sched = _build(dev)
+        loss_fn = DepthLoss()
+        pipe = FeaturePipeline(model, depth, graphs=graphs)
+        bs, losses, nxt = batches(), [], 0
+        for i in range(len(bs)):
+            while len(pipe) < pipe.depth and nxt < len(bs):
+                pipe.submit(bs[nxt][0])
+                nxt += 1
+            losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, bs[i][1].clone(), feats=pipe.next()))
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(), model.batchnorms[3].running_var.cpu().numpy().copy(), pipe
+
+    ref = run(1, False)
+    got = run(2, True)
+    for a, b in zip(got[:3], ref[:3]):
+        np.testing.assert_array_equal(a, b)
+    shapes = sorted((k[0], k[1][0]) for k in got[3]._graphs)
+    assert shapes == [(0, 2), (0, 4), (1, 4)], shapes  # slot 0 saw both batch sizes and keeps both graphs
+
+
 def test_pipelined_dpt_probe_is_bit_identical_to_serial():
     ref = _run(1, "dpt", n=5)
     got = _run(2, "dpt", n=5, graphs=True)
