@@ -165,7 +165,16 @@ class FeaturePipeline:
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
         self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
         if graphs is None:
-            graphs = os.environ.get("MVP_PIPELINE_GRAPHS", "1") != "0"
+            env = os.environ.get("MVP_PIPELINE_GRAPHS")
+            if env is not None:
+                graphs = env != "0"
+            else:
+                # Capture with RCCL work in flight (its watchdog thread queries events) could not be exercised on the one-GPU test pool:
+                # multi-rank jobs launch eagerly unless asked otherwise.  At the per-GPU batch sizes where replay pays (B <= 8) set
+                # MVP_PIPELINE_GRAPHS=1; at B = 16 the run is device-bound either way.
+                import torch.distributed as dist
+
+                graphs = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
         self._graphs = {}  # (slot, shape, dtype, training, engine id) -> dict(calls, graph, static_in, feats, deferred)
 
@@ -204,7 +213,7 @@ class FeaturePipeline:
 
             static_in = torch.empty_like(images)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):  # other threads (allocator, collectives' watchdog) stay free
                 feats, deferred = self._eager(slot, static_in)
             ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred,
                        pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None,

@@ -121,11 +121,10 @@ def validate(model, probe, loader, loss_fn, verbose=True, scale_invariant=False,
     total_loss, count = 0.0, 0
     global_metrics, level_metrics, segments = None, None, []
     with torch.no_grad():
-        for batch in _device_batches(loader, dev, keys=("image", "depth", "snorm", "segmentation")):
-            images = batch["image"].to(dev)
+        # eval-mode forwards mutate nothing: the next batches' forwards run on side streams under this batch's probe + metric kernels
+        for batch, feats in pipelined_features(model, _device_batches(loader, dev, keys=("image", "depth", "snorm", "segmentation")), probe=probe):
             target = batch["depth"].to(dev).contiguous()
             seg = None if is_navi else batch["segmentation"].to(dev)
-            feats = model(images)
             pred = probe(feats)
             pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
             loss = loss_fn(pred, target)
