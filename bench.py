@@ -141,7 +141,7 @@ def parse_args():
     ap.add_argument("--sustained-steps", type=int, default=300, help="extra untimed-by-the-contract leg: the same step for this many more iterations (steady-state clocks); 0 = skip")
     ap.add_argument("--inflight", type=int, default=None,
                     help="frozen-backbone forwards kept in flight on side HIP streams (mvp/pipeline.py); 1 = one serial kernel chain; "
-                         "default: mvp.pipeline.default_depth(probe) = what the trainers use (2 under the linear probe, 1 under DPT)")
+                         "default: mvp.pipeline.default_depth(probe) = what the trainers use (4 batches ahead on 3 streams under the linear probe, 1 under DPT)")
     ap.add_argument("--tiles", default="auto", choices=["auto", "alone", "shared"],
                     help="GEMM tile policy (mvp_gemm_args.tile_policy): auto = what the pipeline selects (shared-chip 128x128 tiles from 3 forwards in flight); "
                          "'shared' with --inflight 1 runs the pipelined run's kernels as one serial chain (profiling)")
@@ -208,7 +208,9 @@ def main():
         class _ProbeName:  # default_depth only looks at the probe's name
             name = f"bindepth_{args.probe}_k"
 
-        eff_depth = args.inflight if args.inflight is not None else default_depth(_ProbeName)
+        from mvp.pipeline import MAX_STREAMS
+
+        eff_depth = min(args.inflight if args.inflight is not None else default_depth(_ProbeName), MAX_STREAMS)  # kernel chains side by side
         # the counters are collected on a serial chain (one kernel on the chip at a time) of the SAME kernel instantiations the timed run launches
         wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe,
               "--tiles", "shared" if (eff_depth >= SHARED_TILES_FROM or args.tiles == "shared") else "alone"]
@@ -275,10 +277,10 @@ def main():
     from mvp.pipeline import SHARED_TILES_FROM, default_depth, shared_tiles
 
     pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else default_depth(probe))
-    if args.tiles == "alone" and pipe.depth >= SHARED_TILES_FROM:
+    if args.tiles == "alone" and pipe.chains >= SHARED_TILES_FROM:
         raise SystemExit("--tiles alone contradicts --inflight >= 3 (the pipeline selects the shared-chip tiles)")
     # the tile policy of the timed run's backbone GEMMs; a serial chain (--inflight 1) can be forced to it for profiling
-    tiles_shared = pipe.depth >= SHARED_TILES_FROM or args.tiles == "shared"
+    tiles_shared = pipe.chains >= SHARED_TILES_FROM or args.tiles == "shared"
     force_shared = args.tiles == "shared"
 
     def run_steps(i0, n, out=None, pipe=pipe):
@@ -323,7 +325,7 @@ def main():
     images_per_s = world * B * args.steps / dt
 
     # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
-    pipeline_info = {"inflight": pipe.depth, "hipgraph_forward": pipe.graphs, "gemm_tiles": "shared-chip (128x128)" if pipe.depth >= 3 else "alone",
+    pipeline_info = {"inflight": pipe.depth, "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": "shared-chip (128x128)" if tiles_shared else "alone",
                      "what": "frozen forwards of upcoming batches run on side HIP streams under the probe step of the current batch; "
                              "every step still runs its own full forward + probe forward/backward/AdamW inside the timed region"}
     if pipe.depth > 1 and not args.no_serial_leg:

@@ -29,8 +29,9 @@ import torch
 
 _SLOT = 0  # slot of the forward being enqueued (host state; kernels are enqueued by one host thread)
 _PIPELINED = False
-_SHARED = False  # >= 3 forwards in flight: the GEMMs pick the tiles meant for a shared chip (mvp_hip.h, MVP_TILES_SHARED)
+_SHARED = False  # >= 3 kernel chains side by side: the GEMMs pick the tiles meant for a shared chip (mvp_hip.h, MVP_TILES_SHARED)
 SHARED_TILES_FROM = 3
+MAX_STREAMS = 3  # side streams = kernel chains running side by side; more than 3 measured slower (4: -14 %)
 
 
 def current_slot() -> int:
@@ -43,16 +44,16 @@ def pipelined() -> bool:
 
 
 def tile_policy() -> int:
-    """mvp_gemm_args.tile_policy of a GEMM launched now: 1 (MVP_TILES_SHARED) inside a forward of a pipeline that keeps three or more
-    forwards in flight, else 0 (MVP_TILES_ALONE)."""
+    """mvp_gemm_args.tile_policy of a GEMM launched now: 1 (MVP_TILES_SHARED) inside a forward of a pipeline that runs three kernel
+    chains side by side, else 0 (MVP_TILES_ALONE)."""
     return 1 if _SHARED else 0
 
 
 @contextlib.contextmanager
-def _slot(i: int, depth: int = 2):
+def _slot(i: int, chains: int = 2):
     global _SLOT, _PIPELINED, _SHARED
     prev = (_SLOT, _PIPELINED, _SHARED)
-    _SLOT, _PIPELINED, _SHARED = i, True, depth >= SHARED_TILES_FROM
+    _SLOT, _PIPELINED, _SHARED = i, True, chains >= SHARED_TILES_FROM
     try:
         yield
     finally:
@@ -107,11 +108,13 @@ def shared_tiles(on: bool = True):
 
 
 def default_depth(probe=None) -> int:
-    """Forwards kept in flight by the trainers and bench.py.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).
-    Otherwise 3, except under a DPT probe.  Measured on MI355X at B=16 (bench.py, img/s): linear probe at 224^2 — one chain
-    5440-5660, two 6380-6450, three 6610 with the same tiles and **7150-7230 with the shared-chip tiles** three or more chains
-    select (tile_policy), four 6210-6340, five 6820-6950, six 6210-7120 (GPU_MAX_HW_QUEUES 8 / 16 change nothing);
-    the DPT probe step — 19 ms of chip-filling convolutions per batch — loses 739-748 -> 699-723 to a forward running beside it."""
+    """Batches whose forward is submitted ahead of the probe step (= buffer slots) in the trainers and bench.py.  They run on
+    min(depth, 3) side streams.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).  Otherwise 4, except under a DPT
+    probe.  Measured on MI355X at B=16 (bench.py, img/s): linear probe at 224^2 — one chain 5440-5660; two chains 6380-6450; three
+    chains 6610 with the same tiles and 7150-7340 with the shared-chip tiles (tile_policy); four chains 6210-6340, five 6820-7030, six
+    6210-7120 (GPU_MAX_HW_QUEUES 8 / 16 change nothing).  Three chains with 4 / 5 / 6 slots — the next forward of a chain starts when
+    the chain's previous one ends, without waiting for that batch's probe step — 7400-7530 / 7390-7570 / 7550; 2 chains + 4 slots
+    6710-6800.  The DPT probe step (19 ms of chip-filling convolutions per batch) loses 739-748 -> 699-723 to a forward beside it."""
     env = os.environ.get("MVP_INFLIGHT")
     if env is not None:
         return max(1, int(env))
@@ -121,7 +124,7 @@ def default_depth(probe=None) -> int:
         # several ranks rehearsing on ONE card (tests, bench.py over gloo): their queues oversubscribe the card's hardware
         # queues and the processes get time-sliced (measured: 150 ms per step instead of 3)
         return 1
-    return 3
+    return 4
 
 
 def _tensors(obj):
@@ -147,7 +150,7 @@ class FeaturePipeline:
     lazily cached operands) and is then captured; later ones replay; the input batch is copied into the graph's static buffer.
     A graph is tied to the engine it was captured from (rebuilt weights invalidate it: new key, new capture)."""
 
-    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None):
+    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None):
         """``run_ahead``: the host may be at most this many forwards ahead of the device (MVP_RUN_AHEAD, default 8; 0 = unbounded).
         The reference's loop syncs every step (``loss.item()``, train_depth.py:143); a loop that never syncs would otherwise queue
         hundreds of launches (and keep their argument buffers alive).  Throughput-neutral on MI355X (tools/micro/pipeline_probe.py,
@@ -159,7 +162,11 @@ class FeaturePipeline:
             depth = 1
         self.model, self.depth = model, depth
         # (stream priorities do not help: the device offers only (0, -1), and high-priority side streams measured the same)
-        self.streams = [torch.cuda.Stream() for _ in range(depth)] if depth > 1 else []
+        # ``depth`` batches are submitted ahead (one buffer slot each); they run on ``streams`` side streams = kernel chains side by side
+        if streams is None:
+            streams = int(os.environ.get("MVP_PIPELINE_STREAMS", str(MAX_STREAMS)))
+        self.chains = max(1, min(depth, int(streams)))
+        self.streams = [torch.cuda.Stream() for _ in range(self.chains)] if depth > 1 else []
         self._queue = collections.deque()
         self._n = 0
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
@@ -183,7 +190,7 @@ class FeaturePipeline:
 
     # ------------------------------------------------------------------ one forward on a slot's stream
     def _eager(self, slot: int, images: torch.Tensor):
-        with _slot(slot, self.depth):
+        with _slot(slot, self.chains):
             _take_deferred()
             feats = _extract(self.model, images)
             return feats, _take_deferred()
@@ -203,28 +210,41 @@ class FeaturePipeline:
         else:
             self._graphs[key] = self._graphs.pop(key)  # most recently used last
         ent["calls"] += 1
+        if ent["graph"] is None and not any(e["graph"] is not None for e in self._graphs.values()):
+            # The very first forward of the pipeline: set up EVERY slot now (the set-up forwards write nothing but the slot's own buffers,
+            # their deferred updates are dropped), so that no capture — each one is a device-wide sync — falls into the run later,
+            # whatever the caller's warm-up length.  Later shapes (an epoch's ragged last batch) are set up lazily per slot.
+            for other in range(self.depth):
+                if other != slot:
+                    okey = (other,) + key[1:]
+                    oent = self._graphs[okey] = dict(calls=0, graph=None)
+                    self._capture(other, s, images, oent, eng)
         if ent["graph"] is None:
-            # First forward of this slot / shape: run it eagerly (it allocates the slot's buffers and builds lazily cached operands —
-            # none of that may happen inside a capture), then capture the very same call for all later batches.  Capturing launches
-            # nothing, so this batch's features are the eager ones; the capture's one-time cost (a device sync) lands here, in the
-            # slot's first call, not in the middle of the run.
-            out = self._eager(slot, images)
-            from .vit import lookup_pack
-
-            static_in = torch.empty_like(images)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):  # other threads (allocator, collectives' watchdog) stay free
-                feats, deferred = self._eager(slot, static_in)
-            ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred,
-                       pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None,
-                       # the graph holds raw addresses of the slot's buffers and of the engine's operands: both stay alive with it
-                       keep=(eng, eng.slot_state(slot) if hasattr(eng, "slot_state") else None))
-            return out
+            return self._capture(slot, s, images, ent, eng)  # (its replay computed this batch's features)
         ent["static_in"].copy_(images, non_blocking=True)
         ent["graph"].replay()
         if ent["pack"] is not None:
             ent["pack"].generation += 1  # the host code that counts rewrites of the packing does not run on a replay
         return ent["feats"], ent["deferred"]
+
+    def _capture(self, slot: int, s, images: torch.Tensor, ent: dict, eng):
+        """Set a slot up for ``images``' shape: an eager forward (allocates the slot's buffers, builds lazily cached operands — none of
+        that may happen inside a capture), the capture of the very same call, and a first replay on ``images`` (a graph's first launch
+        uploads it to the device: that cost belongs here, not in the run).  Returns the replay's (features, deferred updates)."""
+        from .vit import lookup_pack
+
+        self._eager(slot, images)
+        static_in = torch.empty_like(images)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):  # other threads (allocator, collectives' watchdog) stay free
+            feats, deferred = self._eager(slot, static_in)
+        ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred,
+                   pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None,
+                   # the graph holds raw addresses of the slot's buffers and of the engine's operands: both stay alive with it
+                   keep=(eng, eng.slot_state(slot) if hasattr(eng, "slot_state") else None))
+        static_in.copy_(images, non_blocking=True)
+        g.replay()
+        return feats, deferred
 
     def submit(self, images: torch.Tensor) -> None:
         if len(self._queue) >= self.depth:
@@ -240,8 +260,8 @@ class FeaturePipeline:
             self._queue.append((feats, None, ()))
             return
         slot = self._n % self.depth
+        s = self.streams[self._n % len(self.streams)]
         self._n += 1
-        s = self.streams[slot]
         cur = torch.cuda.current_stream()
         # the batch is ready on the caller's stream, and the probe step that read this slot's buffers is already enqueued there
         s.wait_stream(cur)

@@ -56,17 +56,19 @@ def _run(depth, probe_kind="linear", n=7, graphs=False):
             pipe.submit(bs[nxt]["image"])
             nxt += 1
         losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, bs[i]["depth"].clone(), feats=pipe.next()))
-    if graphs:  # every slot went through its eager call, its capture and at least one replay
-        assert len(pipe._graphs) == depth and all(e["graph"] is not None and e["calls"] >= 2 for e in pipe._graphs.values())
+    if graphs:  # every slot was set up (eager run + capture) at the first submit; all later forwards were replays
+        assert len(pipe._graphs) == depth and all(e["graph"] is not None for e in pipe._graphs.values())
+        assert sum(e["calls"] for e in pipe._graphs.values()) == n and max(e["calls"] for e in pipe._graphs.values()) >= 2
     torch.cuda.synchronize()
     bn = [torch.cat([b.running_mean, b.running_var]).cpu().numpy() for b in model.batchnorms]
     nbt = [int(b.num_batches_tracked) for b in model.batchnorms]
     return (torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(), opt.exp_avg_sq.cpu().numpy().copy(), bn, nbt)
 
 
-@pytest.mark.parametrize("depth,graphs", [(2, False), (3, False), (2, True), (3, True)])
+@pytest.mark.parametrize("depth,graphs", [(2, False), (3, False), (2, True), (3, True), (4, True)])
 def test_pipelined_training_is_bit_identical_to_serial(depth, graphs):
-    """depth 3 also switches the backbone GEMMs to the shared-chip tiles (tile_policy): still the same bits.  graphs: every slot's
+    """depth >= 3 also switches the backbone GEMMs to the shared-chip tiles (tile_policy): still the same bits; depth 4 runs its four
+    slots on three streams (a slot's graph replays on whichever stream its turn falls on).  graphs: every slot's
     forward replays a captured hipGraph from its third call on; the tap-BN running statistics are applied by the consumer."""
     ref = _run(1)
     got = _run(depth, graphs=graphs)

@@ -64,7 +64,7 @@ def test_default_depth_env(monkeypatch):
     from mvp import pipeline
 
     monkeypatch.delenv("MVP_INFLIGHT", raising=False)
-    assert pipeline.default_depth() == 3
+    assert pipeline.default_depth() == 4
     monkeypatch.setenv("MVP_INFLIGHT", "1")
     assert pipeline.default_depth() == 1
     monkeypatch.setenv("MVP_INFLIGHT", "0")
@@ -79,7 +79,7 @@ def test_default_depth_by_probe(monkeypatch):
             self.name = name
 
     monkeypatch.delenv("MVP_INFLIGHT", raising=False)
-    assert pipeline.default_depth(P("bindepth_linear_k1")) == 3
+    assert pipeline.default_depth(P("bindepth_linear_k1")) == 4
     assert pipeline.default_depth(P("bindepth_dpt_k3")) == 1
     assert pipeline.default_depth(P("snorm_dpt_k3_UA")) == 1
     monkeypatch.setenv("MVP_INFLIGHT", "3")
