@@ -247,7 +247,11 @@ __global__ __launch_bounds__(SK_NW * 64) void gemm_sk_kernel(const mvp_gemm_args
       const int w_first = (int)(((i0 + 1) * G + T - 1) / T) - 1, w_last = (int)(((i1 + 1) * G + T - 1) / T) - 1;
       const int S = w_last - w_first + 1;
       __syncthreads();
-      if (tid == 0) s_last = (__hip_atomic_fetch_add(ctr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // see gemm.hip: the sc1 stores' vmcnt(0) alone is not enough on a busy chip
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = (__hip_atomic_fetch_add(ctr + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
+      }
       __syncthreads();
       if (!s_last) continue;
       // last arriver: one agent-scope acquire -> vmcnt(0) -> barrier -> sc1 loads (same protocol as gemm.hip's split-K)

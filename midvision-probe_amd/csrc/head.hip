@@ -305,7 +305,9 @@ extern "C" int mvp_linear_bins_fwd(const mvp_linear_bins_args* a, void* stream) 
   if (!a || !a->l0 || !a->depth || !a->inv_sum || !a->gate) return MVP_EINVAL;
   if (a->B <= 0 || a->h <= 0 || a->w <= 0 || a->f < 1 || a->K < 8 || (a->K & 7)) return MVP_EINVAL;
   const int64_t P = (int64_t)a->B * a->h * a->f * a->w * a->f;
-  if (a->K == 256 && a->f <= 4 && P < ((int64_t)1 << 31)) {
+  static const bool generic = getenv("MVP_BINS_GENERIC") != nullptr;  // diagnostic: the one-wave-per-pixel kernel (used to bisect the
+                                                                      // packed-fp32 problem described in the Makefile)
+  if (!generic && a->K == 256 && a->f <= 4 && P < ((int64_t)1 << 31)) {
     const int64_t cells = (int64_t)a->B * (a->h + 1) * (a->w + 1);
     hipLaunchKernelGGL(linear_bins_fwd_cells, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *a);
   } else {

@@ -120,7 +120,10 @@ constexpr int BN_FC = 16, BN_FG = 64;
 // The momentum update of a running statistic, written with explicit roundings (no FMA contraction) so that the in-kernel form and the
 // deferred form (bn_running_update_kernel) give the same bits: (1 - m) * old + m * val, every operation rounded as torch's CPU kernel does.
 __device__ __forceinline__ float bn_running(float old, float val, float momentum) {
-  return __fadd_rn(__fmul_rn(1.f - momentum, old), __fmul_rn(momentum, val));
+#pragma clang fp contract(off)  // (the _rn intrinsics alone were still fused differently in the two kernels by one build)
+  const float a = (1.f - momentum) * old;
+  const float b = momentum * val;
+  return a + b;
 }
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,

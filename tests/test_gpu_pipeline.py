@@ -194,3 +194,52 @@ def test_resnet_forwards_in_flight_match_serial():
             assert torch.equal(u, v)
     for a, b in zip((bn.running_mean for bn in m.batchnorms), ref_rm):
         assert torch.equal(a, b)
+
+
+def test_kernels_reproduce_themselves_beside_mfma_kernels():
+    """Regression for the packed-fp32 finding (csrc/Makefile): the fused bilinear x4 + bin-expectation kernel and the probe's other
+    element-wise stages must return the same bits while 64x64-tile GEMMs run beside them on another stream.  With the SLP-vectorised
+    build 5-10 % of these launches differed in one pixel; 300 launches each here."""
+    from mvp import functional as MF, lib, ops
+    from mvp.lib import PREC_BF16X3
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    a_p = ops.split_bf16(torch.randn(128, 3072, generator=g).to(dev), PREC_BF16X3)
+    w_p = ops.split_bf16((torch.randn(768, 3072, generator=g) * 0.05).to(dev), PREC_BF16X3)
+    out = torch.empty(128, 768, device=dev)
+    side = torch.cuda.Stream()
+    B, h, w, K = 4, 4, 5, 256
+    l0 = torch.randn(B * h * w, K, generator=g).to(dev)
+    small = (torch.rand(4, 1, 16, 20, generator=g) * 9 + 0.1).to(dev)
+    x = torch.randn(84, 768, generator=g).to(dev)
+    gam, bet = torch.ones(768, device=dev), torch.zeros(768, device=dev)
+
+    def bins():
+        P = B * 16 * h * w
+        depth = torch.empty(B, 1, 4 * h, 4 * w, dtype=torch.float32, device=dev)
+        inv = torch.empty(P, dtype=torch.float32, device=dev)
+        gate = torch.empty(P, K // 8, dtype=torch.uint8, device=dev)
+        lib.call("mvp_linear_bins_fwd", lib.LinearBinsArgs(lib.ptr(l0), lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), None, None, B, h, w, K, 4, 0.001, 10.0))
+        return [depth, inv, gate]
+
+    def resize():
+        return [MF.interpolate(small, size=(64, 80), mode="bilinear")]
+
+    def layernorm():
+        o = ops.empty_pair((84, 768), PREC_BF16X3, dev)
+        ops.layernorm(x, gam, bet, o, 84, 768, 1e-6)
+        return list(o)
+
+    for fn in (bins, resize, layernorm):
+        torch.cuda.synchronize()
+        ref = fn()
+        torch.cuda.synchronize()
+        for r in range(300):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    ops.gemm(a_p, w_p, 64, 768, 768, out_f32=out, lda=3072, ldw=3072)
+            got = fn()
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), f"{fn.__name__}: launch {r} differs beside the GEMM load"
+        torch.cuda.synchronize()
