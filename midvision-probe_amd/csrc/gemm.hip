@@ -354,8 +354,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
     // Cross-workgroup hand-over: partials leave with 16-byte `sc1` (write-through) stores that the storing wave waits for (vmcnt(0));
     // after the workgroup barrier ONE lane runs an agent-scope release and the workgroup's ONE agent-scope atomic add; only the
     // workgroup whose add returned S-1 (it came last) pays one agent-scope acquire, then reads all partials with `sc1` loads
-    // (MI355X_MICROARCH.md, "Valid forms").  A release per workgroup is affordable here because split-K is no longer chosen
-    // automatically: it serves explicit requests for few-tile, long-K shapes.
+    // (MI355X_MICROARCH.md, "Valid forms").  A release per workgroup is affordable here: split-K serves few-tile, long-K shapes only.
     int* ctr = (int*)p.splitk_ws;
     constexpr int NACC = NT * MT;
     constexpr int UNIT_BYTES = NACC * NT_THREADS * 16;  // [acc register][thread] float4: 1-KiB wave accesses
@@ -373,10 +372,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
     __shared__ int s_last;
     __syncthreads();
     if (tid == 0) {
-      // Agent-scope RELEASE before the counter add.  Round 1 relied on the sc1 stores' vmcnt(0) alone (measured valid on an otherwise
-      // idle chip); with other kernel chains running beside this launch (mvp/pipeline.py) the last arriver read a partial that had not
-      // landed yet in 2 of 15 seven-step trajectories (tools/micro/race_hunt.py: the previous launch's partial of the same tile, a
-      // 1e-6 loss difference).  buffer_wbl2 + the explicit wait make the hand-over the architecturally specified one.
+      // Agent-scope RELEASE before the counter add: the architecturally specified hand-over.  (Round 1 relied on the sc1 stores'
+      // vmcnt(0) alone, measured valid on an idle chip; the release was added while pipelined runs were being bisected — the
+      // culprit turned out to be packed fp32 elsewhere, csrc/Makefile — and stays: 1500 trajectories beside other chains are exact.)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait: MI355X_MICROARCH.md, compiler hazard)
       s_last = (__hip_atomic_fetch_add(ctr + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;

@@ -94,12 +94,16 @@ _SPLITK_WS = {}  # (device, stream) -> zero-initialised workspace (tile counters
 
 
 def splitk_auto(M: int, N: int, K: int) -> int:
-    """Split-K factor used when the caller does not give one: none.  Round 1 split the probe head at small M 4 ways (skinny N <= 256,
-    long K, <= 128 tiles: 52.5 -> 40.4 us inside the serial step at B=16).  Its partial-tile hand-over inside one launch (sc1 stores,
-    one relaxed agent atomic, last arriver reduces) was bit-reproducible on an idle chip but read a not-yet-landed partial in 2 of 15
-    short trajectories once other kernel chains ran beside it (mvp/pipeline.py; tools/micro/race_hunt.py).  The kernel now releases at
-    agent scope before its counter add, and nothing selects it by default: 12 us of a probe step that runs under other chains' GEMMs
-    is not worth an intra-launch hand-over on the training path.  ``gemm(..., splitk=S)`` still requests it."""
+    """Split-K factor used when the caller does not give one.  Measured on MI355X (tools/splitk_bench.py and in-step,
+    bf16x3): the N = 768 projections do NOT profit (proj 27.1 us unsplit vs 33.6 at S=2; fc2 71.8 vs 77.3): they are
+    bound by the L2->LDS operand path, not by tile imbalance.  The one shape that does is the probe head at small M
+    (skinny N <= 256, long K, <= 128 tiles): its A operand was just written by the tap kernels and comes from HBM /
+    Infinity Cache, and 4x more workgroups pull it 4x wider: 52.5 -> 40.4 us inside the step at B=16.
+    (The intra-launch partial-tile hand-over was suspected when pipelined trajectories stopped reproducing the serial ones; the cause
+    was elsewhere — csrc/Makefile, packed fp32 — and 1500 trajectories with this rule beside other kernel chains are bit-exact,
+    tools/micro/race_hunt2.py VAR=splitk.  The hand-over carries an agent-scope release since.)"""
+    if N <= 256 and K >= 2048 and ((M + 127) // 128) * ((N + 63) // 64) <= 128:
+        return 4
     return 1
 
 

@@ -14,6 +14,9 @@ from mvp.pipeline import FeaturePipeline
 from mvp.train import train_depth_step
 
 VAR = set(os.environ.get("VAR", "").split(",")) - {""}
+if "splitk" in VAR:  # round 1's automatic 4-way split-K of the probe head GEMM
+    from mvp import ops as _ops
+    _ops.splitk_auto = lambda M, N, K: 4 if (N <= 256 and K >= 2048 and ((M + 127) // 128) * ((N + 63) // 64) <= 128) else 1
 dev = torch.device("cuda:0")
 n = int(os.environ.get("STEPS", "7"))
 B = int(os.environ.get("B", "4"))
