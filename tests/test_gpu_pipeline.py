@@ -243,3 +243,47 @@ def test_kernels_reproduce_themselves_beside_mfma_kernels():
             got = fn()
             assert all(torch.equal(a, b) for a, b in zip(got, ref)), f"{fn.__name__}: launch {r} differs beside the GEMM load"
         torch.cuda.synchronize()
+
+
+def test_train_and_validate_loops_match_the_serial_loops(monkeypatch):
+    """mvp.train.train() / validate() with their default pipelines (4 batches ahead on 3 streams, replayed graphs; eval-mode forwards
+    in flight during validation) against the same loops forced serial (MVP_INFLIGHT=1): same loss history, same probe weights, same
+    BN running statistics, same validation loss and metrics."""
+    from evals.utils.losses import DepthLoss
+    from mvp.train import train, validate
+
+    dev = torch.device("cuda:0")
+
+    class Loader(list):
+        sampler = None
+
+    def batches(n, seed):
+        out = []
+        for s in range(n):
+            g = torch.Generator().manual_seed(seed + s)
+            img = torch.randn(4, 3, 64, 80, generator=g)
+            dep = torch.rand(4, 1, 64, 80, generator=g) * 9.0 + 0.05
+            seg = torch.randint(0, 150, (4, 64, 80), generator=g)
+            out.append({"image": img.to(dev), "depth": dep.to(dev), "segmentation": seg.to(dev)})
+        return Loader(out)
+
+    def run():
+        model, probe, opt, sched = _build(dev)
+        hist = train(model, probe, batches(9, 100), opt, sched, 2, True, DepthLoss())
+        opt.finish_pending()
+        model.eval(); probe.eval()
+        vloss, gm, lm = validate(model, probe, batches(5, 300), DepthLoss(), verbose=False)
+        torch.cuda.synchronize()
+        return (hist, opt.flat_param.cpu().numpy().copy(), model.batchnorms[2].running_var.cpu().numpy().copy(), float(vloss),
+                {k: float(v) for k, v in gm.items()})
+
+    monkeypatch.setenv("MVP_INFLIGHT", "1")
+    ref = run()
+    monkeypatch.delenv("MVP_INFLIGHT")
+    got = run()
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    assert got[3] == ref[3]
+    for k, v in ref[4].items():  # (the per-level / per-segment reductions add in hardware-atomic order: last bits may move)
+        assert got[4][k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
