@@ -302,6 +302,10 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
     t+1 is enqueued before batch t is handed to the caller, so it runs under the caller's probe step t.  ``depth`` None:
     ``default_depth(probe)``."""
     pipe = FeaturePipeline(model, default_depth(probe) if depth is None else depth)
+    if hasattr(batches, "consumer_lag"):
+        # mvp.prefetch.DevicePrefetcher recycles its device buffers: this generator holds pipe.depth batches before the caller has
+        # issued the probe step of the first of them (which reads that batch's target; its image is read by the forward in flight)
+        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth - 1)
     it = iter(batches)
     pending = collections.deque()
 

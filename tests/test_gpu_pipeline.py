@@ -287,3 +287,35 @@ def test_train_and_validate_loops_match_the_serial_loops(monkeypatch):
     assert got[3] == ref[3]
     for k, v in ref[4].items():  # (the per-level / per-segment reductions add in hardware-atomic order: last bits may move)
         assert got[4][k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
+
+
+def test_prefetcher_buffers_survive_the_pipelines_look_ahead():
+    """DevicePrefetcher recycles its device buffers; pipelined_features pulls 4 batches before it issues the first probe step.  The
+    prefetcher must not overwrite a batch's target (read by the probe step) or image (read by the forward in flight) while the pipeline
+    still holds it: 14 distinct host batches through prefetcher + pipeline == the same batches through the serial loop."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import pipelined_features
+    from mvp.prefetch import DevicePrefetcher
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    host = []
+    for s in range(14):
+        g = torch.Generator().manual_seed(700 + s)
+        host.append({"image": torch.randn(4, 3, 64, 80, generator=g).pin_memory(), "depth": (torch.rand(4, 1, 64, 80, generator=g) * 9 + 0.05).pin_memory()})
+
+    def run(depth):
+        model, probe, opt, sched = _build(dev)
+        loss_fn = DepthLoss()
+        pre = DevicePrefetcher(host, dev, depth=2)
+        losses = []
+        for batch, feats in pipelined_features(model, pre, depth=depth):
+            losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, batch["depth"], feats=feats))
+        torch.cuda.synchronize()
+        assert pre.consumer_lag == depth - 1
+        return torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy()
+
+    ref = run(1)
+    got = run(4)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
