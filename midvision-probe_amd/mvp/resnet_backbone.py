@@ -68,6 +68,7 @@ class ResNetParams(nn.Module):
 class ResNetBackbone(nn.Module):
     feat_dims_all = [(64, 240), (256, 120), (512, 60), (1024, 30), (2048, 15)]  # nominal (quirk Q8)
     supports_pipelining = True  # the engine allocates per forward on the launching stream and defers the tap-BN running-statistics updates to the consumer (mvp/pipeline.py)
+    graph_safe = True  # per-forward buffers come from the capturing graph's private pool: a slot's forward replays on fixed addresses
 
     def _setup(self, sd, output, return_layers, return_multilayer, add_norm, fixed_size, precision):
         self.model = ResNetParams(sd).eval()

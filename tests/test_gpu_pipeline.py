@@ -183,8 +183,8 @@ def test_resnet_forwards_in_flight_match_serial():
     ref = [[t.clone() for t in m(x)] for x in xs]
     ref_rm = [b.running_mean.clone() for b in m.batchnorms]
     m = build()
-    pipe = FeaturePipeline(m, 3)
-    assert pipe.depth == 3
+    pipe = FeaturePipeline(m, 3, graphs=False)
+    assert pipe.depth == 3 and not pipe.graphs
     for x in xs:
         pipe.submit(x)
     got = [[t.clone() for t in pipe.next()] for _ in xs]
@@ -193,6 +193,23 @@ def test_resnet_forwards_in_flight_match_serial():
         for u, v in zip(a, b):
             assert torch.equal(u, v)
     for a, b in zip((bn.running_mean for bn in m.batchnorms), ref_rm):
+        assert torch.equal(a, b)
+    # replayed graphs (per-forward buffers live in each graph's private pool): two rounds over the same batches, the second all replays
+    m = build()
+    ref2 = [[t.clone() for t in m(x)] for x in xs + xs]
+    ref2_rv = [b.running_var.clone() for b in m.batchnorms]
+    m = build()
+    pipe = FeaturePipeline(m, 2, graphs=True)
+    assert pipe.graphs
+    got2 = []
+    for x in xs + xs:
+        pipe.submit(x)
+        got2.append([t.clone() for t in pipe.next()])
+    torch.cuda.synchronize()
+    for a, b in zip(got2, ref2):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    for a, b in zip((bn.running_var for bn in m.batchnorms), ref2_rv):
         assert torch.equal(a, b)
 
 

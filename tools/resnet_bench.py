@@ -20,3 +20,27 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"ResNet-50 multilayer extract B={B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} img/s, taps {[tuple(o.shape) for o in out]}")
+
+# the same forwards kept in flight (mvp/pipeline.py: INFLIGHT batches ahead on up to 3 side streams, eager launches)
+if os.environ.get("INFLIGHT", "4") != "1":
+    from mvp.pipeline import FeaturePipeline
+
+    for depth, streams, graphs in ((2, 2, False), (4, 3, False), (4, 3, True)):
+        pipe = FeaturePipeline(m, depth, streams=streams, graphs=graphs)
+        xs = [torch.randn(B, 3, 224, 224, device=dev) for _ in range(4)]
+
+        def run(n):
+            nxt = 0
+            for i in range(n):
+                while len(pipe) < pipe.depth and nxt < n:
+                    pipe.submit(xs[nxt % 4])
+                    nxt += 1
+                pipe.next()
+
+        run(8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(40)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 40
+        print(f"ResNet-50 multilayer extract B={B}, {depth} batches ahead on {pipe.chains} streams, hipGraph replay {pipe.graphs}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} img/s")
