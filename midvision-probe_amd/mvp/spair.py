@@ -47,20 +47,32 @@ def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
         # the reference multiplies feats [2,C,h,w] by masks [2,h,w] (evaluate_spair_correspondence.py:61-62): that broadcast only
         # type-checks for C == 2, i.e. it raises for every real backbone; no caller in the reference passes mask_feats=True
         raise NotImplementedError("mask_feats=True does not broadcast in the reference either (feats [2,C,h,w] * masks [2,h,w])")
-    img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _ = instance
-    dev = torch.device("cuda", torch.cuda.current_device())
-    images = torch.stack((img_i, img_j)).to(dev)
+    images, kps_i, kps_j, thresh_scale = _pair_inputs(instance)
     feats = model(images)  # NB: the reference runs this outside no_grad with the wrapper in train mode
     if isinstance(feats, list):
         feats = torch.cat(feats, dim=1)
+    res = correspondence(feats[0], feats[1], kps_i[:, :2], return_heatmaps=return_heatmaps)
+    out = _pck_rows(res[0].float().cpu() / feats.shape[-1], kps_i, kps_j, thresh_scale)
+    if return_heatmaps:
+        return (*out, res[2])
+    return out
+
+
+def _pair_inputs(instance):
+    """(images [2,3,S,S] on the device, kps_i, kps_j with (x, y) scaled to [0,1], thresh_scale): evaluate_spair_correspondence.py:47-60."""
+    img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _ = instance
+    dev = torch.device("cuda", torch.cuda.current_device())
+    images = torch.stack((img_i, img_j)).to(dev)
     assert images.shape[-1] == images.shape[-2], "assuming square images here"
     kps_i = kps_i.float().clone()
     kps_j = kps_j.float().clone()
     kps_i[:, :2] = kps_i[:, :2] / images.shape[-1]
     kps_j[:, :2] = kps_j[:, :2] / images.shape[-1]
-    res = correspondence(feats[0], feats[1], kps_i[:, :2], return_heatmaps=return_heatmaps)
-    pred_xy = res[0]
-    pred_kp = pred_xy.float().cpu() / feats.shape[-1]
+    return images, kps_i, kps_j, thresh_scale
+
+
+def _pck_rows(pred_kp: torch.Tensor, kps_i: torch.Tensor, kps_j: torch.Tensor, thresh_scale):
+    """Host-side PCK bookkeeping of one pair (evaluate_spair_correspondence.py:86-98) from the predicted keypoints in [0,1]."""
     errors = (pred_kp[:, None, :] - kps_j[None, :, :2]).norm(p=2, dim=-1)
     errors = errors / thresh_scale
     valid_kps = (kps_i[:, None, 2] * kps_j[None, :, 2]) == 1
@@ -69,8 +81,6 @@ def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
     error_same = errors.diagonal()[in_both]
     error_nn, index_nn = errors[in_both].min(dim=1)
     index_same = in_both.nonzero().squeeze(1)
-    if return_heatmaps:
-        return error_same, error_nn, index_same, index_nn, res[2]
     return error_same, error_nn, index_same, index_nn
 
 
@@ -85,7 +95,23 @@ def evaluate_dataset(model, dataset, thresh, verbose=False, rank: int = 0, world
     (rank r takes pairs r, r + W, ...; pairs are independent) and the per-pair error / index vectors are gathered with
     one all_gather_object at the end (host-side lists of a few floats per pair), so every rank returns the full-dataset result."""
     idx = shard_pairs(len(dataset), rank, world)
-    outs = [(i,) + tuple(t.cpu() for t in compute_errors(model, dataset[i])) for i in idx]
+    # The pairs' forwards are kept in flight (mvp/pipeline.py; pairs are independent, the wrapper's train-mode tap BN sees one pair at a
+    # time and its running statistics are updated in pair order), the correspondence kernel of pair t runs under the forwards of the
+    # next pairs, and the predicted keypoints stay on the device until the end: one host sync per shard instead of one per pair.
+    from .pipeline import pipelined_features
+
+    def pairs():
+        for i in idx:
+            images, kps_i, kps_j, thresh_scale = _pair_inputs(dataset[i])
+            yield {"image": images, "meta": (i, kps_i, kps_j, thresh_scale)}
+
+    pending = []
+    for b, feats in pipelined_features(model, pairs()):
+        f = torch.cat(list(feats), dim=1) if isinstance(feats, (list, tuple)) else feats
+        i, kps_i, kps_j, thresh_scale = b["meta"]
+        pred_xy, _ = correspondence(f[0], f[1], kps_i[:, :2])
+        pending.append((i, pred_xy, f.shape[-1], kps_i, kps_j, thresh_scale))
+    outs = [(i,) + _pck_rows(pred_xy.float().cpu() / fw, kps_i, kps_j, ts) for i, pred_xy, fw, kps_i, kps_j, ts in pending]
     if world > 1:
         import torch.distributed as dist
 
