@@ -58,11 +58,37 @@ def compute_errors(model, instance, mask_feats=False, return_heatmaps=False):
     return out
 
 
-def _pair_inputs(instance):
+class _PinnedRing:
+    """Host -> device staging through a few reused pinned buffers: the copy engine moves them asynchronously, where a pageable
+    ``.to(device)`` blocks the host until the copy has run (and with it the whole look-ahead of the pipeline)."""
+
+    def __init__(self, slots: int):
+        self.slots, self.k = [dict() for _ in range(max(2, slots))], 0
+
+    def to_device(self, parts, dev, dtype=torch.float32) -> torch.Tensor:
+        """torch.stack(parts) on the device."""
+        slot = self.slots[self.k % len(self.slots)]
+        self.k += 1
+        shape = (len(parts),) + tuple(parts[0].shape)
+        ev = slot.get("event")
+        if ev is not None:
+            ev.synchronize()  # the copy that last read this pinned buffer has finished (normally long ago)
+        buf = slot.get("buf")
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != dtype:
+            buf = slot["buf"] = torch.empty(shape, dtype=dtype).pin_memory()
+        torch.stack([p.to(dtype) for p in parts], out=buf)
+        out = torch.empty(shape, dtype=dtype, device=dev)
+        out.copy_(buf, non_blocking=True)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record()
+        return out
+
+
+def _pair_inputs(instance, ring: "_PinnedRing" = None):
     """(images [2,3,S,S] on the device, kps_i, kps_j with (x, y) scaled to [0,1], thresh_scale): evaluate_spair_correspondence.py:47-60."""
     img_i, mask_i, kps_i, img_j, mask_j, kps_j, thresh_scale, _ = instance
     dev = torch.device("cuda", torch.cuda.current_device())
-    images = torch.stack((img_i, img_j)).to(dev)
+    images = torch.stack((img_i, img_j)).to(dev) if ring is None else ring.to_device((img_i, img_j), dev)
     assert images.shape[-1] == images.shape[-2], "assuming square images here"
     kps_i = kps_i.float().clone()
     kps_j = kps_j.float().clone()
@@ -100,16 +126,19 @@ def evaluate_dataset(model, dataset, thresh, verbose=False, rank: int = 0, world
     # next pairs, and the predicted keypoints stay on the device until the end: one host sync per shard instead of one per pair.
     from .pipeline import pipelined_features
 
+    ring = _PinnedRing(8)  # images and keypoints go through pinned staging: nothing in the loop blocks the host
+
     def pairs():
         for i in idx:
-            images, kps_i, kps_j, thresh_scale = _pair_inputs(dataset[i])
-            yield {"image": images, "meta": (i, kps_i, kps_j, thresh_scale)}
+            images, kps_i, kps_j, thresh_scale = _pair_inputs(dataset[i], ring)
+            kp_dev = ring.to_device((kps_i[:, :2].contiguous(),), images.device)[0]
+            yield {"image": images, "meta": (i, kps_i, kps_j, thresh_scale, kp_dev)}
 
     pending = []
     for b, feats in pipelined_features(model, pairs()):
         f = torch.cat(list(feats), dim=1) if isinstance(feats, (list, tuple)) else feats
-        i, kps_i, kps_j, thresh_scale = b["meta"]
-        pred_xy, _ = correspondence(f[0], f[1], kps_i[:, :2])
+        i, kps_i, kps_j, thresh_scale, kp_dev = b["meta"]
+        pred_xy, _ = correspondence(f[0], f[1], kp_dev)
         pending.append((i, pred_xy, f.shape[-1], kps_i, kps_j, thresh_scale))
     outs = [(i,) + _pck_rows(pred_xy.float().cpu() / fw, kps_i, kps_j, ts) for i, pred_xy, fw, kps_i, kps_j, ts in pending]
     if world > 1:
