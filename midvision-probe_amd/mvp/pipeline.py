@@ -287,8 +287,12 @@ class FeaturePipeline:
         return feats
 
     def drain(self) -> None:
+        """Discard the forwards still in flight (a loop left early): the caller's stream waits for them, their deferred state updates
+        are NOT applied — as if those batches had never been run, which is what the one-batch-at-a-time loop would have done."""
         while self._queue:
-            self.next()
+            feats, done, deferred = self._queue.popleft()
+            if done is not None:
+                torch.cuda.current_stream().wait_event(done)
 
 
 def _extract(model, images):

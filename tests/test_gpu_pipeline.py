@@ -336,3 +336,28 @@ def test_prefetcher_buffers_survive_the_pipelines_look_ahead():
     got = run(4)
     np.testing.assert_array_equal(got[0], ref[0])
     np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_leaving_the_loop_early_discards_the_forwards_in_flight():
+    """A loop that breaks after 3 batches has 3 more forwards in flight: their tap-BN running-statistics updates must not be applied
+    (the one-at-a-time loop would never have run them)."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import pipelined_features
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+
+    def run(depth):
+        model, probe, opt, sched = _build(dev)
+        loss_fn = DepthLoss()
+        for i, (batch, feats) in enumerate(pipelined_features(model, _batches(dev, 9), depth=depth)):
+            train_depth_step(model, probe, opt, sched, loss_fn, None, batch["depth"].clone(), feats=feats)
+            if i == 2:
+                break
+        torch.cuda.synchronize()
+        return [int(b.num_batches_tracked) for b in model.batchnorms], model.batchnorms[1].running_mean.cpu().numpy().copy(), opt.flat_param.cpu().numpy().copy()
+
+    ref, got = run(1), run(4)
+    assert ref[0] == got[0] == [3] * 4
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
