@@ -54,6 +54,49 @@ __global__ __launch_bounds__(256) void pk(unsigned long long* bad, unsigned long
   if (threadIdx.x == 0) atomicAdd(total, (unsigned long long)iters * 512ull);
 }
 
+// v_pk_add_f32 (no lane selects): what a packed fp32 SUM reduction uses (RCCL's gfx950 code object contains 108 of them)
+__global__ __launch_bounds__(256) void pkadd(unsigned long long* bad, unsigned long long* total, int iters, unsigned seed) {
+  unsigned s = seed ^ (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) * (1.0f / 65536.0f) - 0.5f; };
+  unsigned long long nbad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const f2 a = {rnd(), rnd()}, b = {rnd(), rnd()}, c = {rnd(), rnd()};
+    f2 d, e2;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(e2) : "v"(d), "v"(c));
+    const float r0 = (a.x + b.x) + c.x, r1 = (a.y + b.y) + c.y;
+    nbad += (__float_as_uint(e2.x) != __float_as_uint(r0)) + (__float_as_uint(e2.y) != __float_as_uint(r1));
+  }
+  if (nbad) atomicAdd(bad, nbad);
+  if (threadIdx.x == 0) atomicAdd(total, (unsigned long long)iters * 512ull);
+}
+
+// One packed form at a time: v_pk_mul_f32, v_pk_fma_f32 without lane selects, v_pk_fma_f32 with the crossed lane select
+template <int FORM>
+__global__ __launch_bounds__(256) void pkform(unsigned long long* bad, unsigned long long* total, int iters, unsigned seed) {
+  unsigned s = seed ^ (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) * (1.0f / 65536.0f) - 0.5f; };
+  unsigned long long nbad = 0;
+  for (int it = 0; it < iters; ++it) {
+    const f2 a = {rnd(), rnd()}, b = {rnd(), rnd()}, c = {rnd(), rnd()};
+    f2 d;
+    float r0, r1;
+    if (FORM == 0) {
+      asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+      r0 = a.x * b.x; r1 = a.y * b.y;
+    } else if (FORM == 1) {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+      r0 = __builtin_fmaf(a.x, b.x, c.x); r1 = __builtin_fmaf(a.y, b.y, c.y);
+    } else {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+      r0 = __builtin_fmaf(a.x, b.y, c.x); r1 = __builtin_fmaf(a.y, b.x, c.y);
+    }
+    nbad += (__float_as_uint(d.x) != __float_as_uint(r0)) + (__float_as_uint(d.y) != __float_as_uint(r1));
+  }
+  if (nbad) atomicAdd(bad, nbad);
+  if (threadIdx.x == 0) atomicAdd(total, (unsigned long long)iters * 512ull);
+}
+
 // Controls: the same blend computed twice with SCALAR v_mul / v_fma (an opaque asm barrier keeps the compiler from merging the two),
 // and v_cvt_pk_bf16_f32 (the conversion every epilogue of the library uses) against integer round-to-nearest-even.
 __global__ __launch_bounds__(256) void ctl(unsigned long long* bad, unsigned long long* total, int iters, unsigned seed) {
@@ -166,7 +209,7 @@ int main(int argc, char** argv) {
   }
   char* dsrc; hipMalloc(&dsrc, 1 << 20); hipMemset(dsrc, 1, 1 << 20);
   hipFuncSetAttribute((const void*)dma_load, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
-  for (int which = 0; which < 2; ++which)
+  for (int which = 0; which < 6; ++which)
   for (int mode = 0; mode < (gemm ? 6 : 2); ++mode) {
     hipMemset(bad, 0, 8); hipMemset(total, 0, 8);
     hipDeviceSynchronize();
@@ -177,12 +220,16 @@ int main(int argc, char** argv) {
       if (mode == 4) hipLaunchKernelGGL(mfma_agpr_load, dim3(2048), dim3(256), 0, s2, sink, 2000);
       if (mode == 5) hipLaunchKernelGGL(mfma_lds_load, dim3(2048), dim3(256), 0, s2, sink, 1000);
       if (which == 0) hipLaunchKernelGGL(pk, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
-      else hipLaunchKernelGGL(ctl, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
+      else if (which == 1) hipLaunchKernelGGL(ctl, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
+      else if (which == 2) hipLaunchKernelGGL(pkadd, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
+      else if (which == 3) hipLaunchKernelGGL(pkform<0>, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
+      else if (which == 4) hipLaunchKernelGGL(pkform<1>, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
+      else hipLaunchKernelGGL(pkform<2>, dim3(30), dim3(256), 0, s1, bad, total, 400, (unsigned)rep * 7919u + 1u);
     }
     hipDeviceSynchronize();
     unsigned long long hb = 0, ht = 0;
     hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost); hipMemcpy(&ht, total, 8, hipMemcpyDeviceToHost);
-    printf("%s, mode %d (%s): %llu results differ out of %llu\n", which == 0 ? "packed fp32 vs scalar" : "control: scalar fp32 twice + v_cvt_pk_bf16_f32", mode,
+    printf("%s, mode %d (%s): %llu results differ out of %llu\n", which == 0 ? "packed fp32 vs scalar" : which == 1 ? "control: scalar fp32 twice + v_cvt_pk_bf16_f32" : which == 2 ? "v_pk_add_f32 vs scalar add" : which == 3 ? "v_pk_mul_f32 alone" : which == 4 ? "v_pk_fma_f32 (no op_sel) alone" : "v_pk_fma_f32 op_sel alone", mode,
            mode == 0 ? "packed-fp32 kernel alone" : mode == 1 ? "beside an MFMA loop kernel" : mode == 2 ? "beside the library's 64x64 GEMM" : mode == 3 ? "beside an LDS-DMA loop kernel" : mode == 4 ? "beside an MFMA loop with AccVGPR accumulators" : "beside an MFMA loop fed by ds_read_b128", hb, ht);
   }
   return 0;
