@@ -15,6 +15,7 @@ sample of the same workload).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -145,6 +146,7 @@ def parse_args():
     ap.add_argument("--tiles", default="auto", choices=["auto", "alone", "shared"],
                     help="GEMM tile policy (mvp_gemm_args.tile_policy): auto = what the pipeline selects (shared-chip 128x128 tiles from 3 forwards in flight); "
                          "'shared' with --inflight 1 runs the pipelined run's kernels as one serial chain (profiling)")
+    ap.add_argument("--group", type=int, default=None, help="batches stacked into one frozen forward (default: mvp.pipeline.default_group)")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra inflight=1 leg reported as pipeline.serial (profiling runs)")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
@@ -276,29 +278,31 @@ def main():
 
     from mvp.pipeline import SHARED_TILES_FROM, default_depth, shared_tiles
 
-    pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else default_depth(probe))
+    # forwards in flight: --inflight (None = the trainers' default: mvp.pipeline.default_depth / default_group), --group batches per forward
+    d0 = default_depth(probe)
+    pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else (d0 if (d0 == 1 or os.environ.get("MVP_INFLIGHT") is not None) else None),
+                           group=args.group)
+    pipe.resolve_group(batches[0][0])
     if args.tiles == "alone" and pipe.chains >= SHARED_TILES_FROM:
         raise SystemExit("--tiles alone contradicts --inflight >= 3 (the pipeline selects the shared-chip tiles)")
     # the tile policy of the timed run's backbone GEMMs; a serial chain (--inflight 1) can be forced to it for profiling
     tiles_shared = pipe.chains >= SHARED_TILES_FROM or args.tiles == "shared"
     force_shared = args.tiles == "shared"
 
+    from mvp.pipeline import pipelined_features
+
     def run_steps(i0, n, out=None, pipe=pipe):
-        """Steps i0 .. i0+n-1, every one the full train_depth.py:99-143 body.  Up to ``inflight`` frozen forwards are in flight on side
-        streams while the probe steps run in order on this stream; the pipeline starts empty and ends empty, so all the work of these n
-        steps (n forwards, n probe forward/backward/AdamW) lies between the caller's two barriers."""
-        nxt = i0
-        for i in range(i0, i0 + n):
-            while len(pipe) < pipe.depth and nxt < i0 + n:
-                if pipe.depth == 1 and force_shared:  # (a pipelined forward selects its policy itself)
-                    with shared_tiles(True):
-                        pipe.submit(batches[nxt % n_distinct][0])
-                else:
-                    pipe.submit(batches[nxt % n_distinct][0])
-                nxt += 1
-            loss = train_depth_step(model, probe, opt, sched, loss_fn, None, batches[i % n_distinct][1], feats=pipe.next())
-            if out is not None:
-                out.append(loss)
+        """Steps i0 .. i0+n-1, every one the full train_depth.py:99-143 body.  The frozen forwards of upcoming batches (stacked ``group``
+        at a time) are in flight on side streams while the probe steps run in order on this stream; the pipeline starts empty and ends
+        empty, so all the work of these n steps (the forwards of n batches, n probe forward/backward/AdamW) lies between the caller's two
+        barriers."""
+        seq = [batches[i % n_distinct] for i in range(i0, i0 + n)]
+        ctx = shared_tiles(True) if (pipe.depth == 1 and force_shared) else contextlib.nullcontext()  # (a pipelined forward selects its policy itself)
+        with ctx:
+            for (images, target), feats in pipelined_features(model, seq, pipe=pipe):
+                loss = train_depth_step(model, probe, opt, sched, loss_fn, None, target, feats=feats)
+                if out is not None:
+                    out.append(loss)
 
     def barrier():
         opt.finish_pending()  # the last step's update belongs to the timed region
@@ -325,9 +329,10 @@ def main():
     images_per_s = world * B * args.steps / dt
 
     # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
-    pipeline_info = {"inflight": pipe.depth, "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": "shared-chip (128x128)" if tiles_shared else "alone",
-                     "what": "frozen forwards of upcoming batches run on side HIP streams under the probe step of the current batch; "
-                             "every step still runs its own full forward + probe forward/backward/AdamW inside the timed region"}
+    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": "shared-chip (128x128)" if tiles_shared else "alone",
+                     "what": "frozen forwards of upcoming batches (stacked `group` at a time into one chain of launches: same bits per batch) run on side "
+                             "HIP streams under the probe steps of the current batches; every step still runs its own full forward + probe "
+                             "forward/backward/AdamW inside the timed region, and the pipeline is empty at both of its barriers"}
     if pipe.depth > 1 and not args.no_serial_leg:
         serial_pipe = FeaturePipeline(model, 1)
         barrier()
@@ -422,7 +427,7 @@ def main():
         dom = max(groups.items(), key=lambda kv: kv[1][1])
         (kind, tile), (fl, sec, cnt) = dom
         achieved = fl / sec / 1e12
-        name = f"gemm_kernel<{tile}>" if kind == "gemm" else "attention_kernel"
+        name = ("gemm_pp_kernel<" + tile[3:] + ">" if tile.startswith("pp ") else f"gemm_kernel<{tile}>") if kind == "gemm" else "attention_kernel"
         default_wl = (B, H, W, args.precision, args.probe) == (16, 224, 224, "bf16x3", "linear")
         traffic, traffic_src, busy = None, None, None
         if pmc_live:

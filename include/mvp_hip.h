@@ -50,7 +50,7 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 3
+#define MVP_ABI_VERSION 4
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
 int mvp_sizeof(const char* struct_name); /* sizeof(<struct_name>) as compiled into the library, -1 if unknown: for bindings to self-check */
@@ -143,11 +143,29 @@ typedef struct {
    *   flight): 128x128 tiles everywhere.  They need 31 % less SIMD time per output (an LDS-DMA piece costs its SIMD ~5 MFMAs, and a
    *   128x128 tile issues 6 MFMAs per piece against 3), and the CUs their coarse grid leaves idle are filled by the other chains. */
   int tile_policy;
+  /* --- layout of the bf16-pair operands A and W (MVP_PREC_BF16X3 only):
+   * MVP_PAIR_SEPARATE (0): a_hi / a_lo and w_hi / w_lo are separate K-contiguous arrays (what every producer of this library writes);
+   * MVP_PAIR_A_ILV32 (1) / MVP_PAIR_W_ILV32 (2), or-ed: that operand is ONE array, hi | lo interleaved per 32-deep k block — row =
+   *   [k / 32][hi 32 | lo 32] bf16, so a 32-deep k-step of a row is one whole 128-byte line; a_hi (w_hi) points at the array, lda
+   *   (ldw) is its row stride in elements (2 * K when dense), a_lo (w_lo) is ignored.  Only the large-M kernel (mvp_gemm_pp) reads
+   *   this layout; MVP_PAIR_ILV32 (3) = both operands.                                                                           */
+  int pair_layout;
 } mvp_gemm_args;
 #define MVP_TILES_ALONE 0
 #define MVP_TILES_SHARED 1
+#define MVP_TILES_NO_PP 2 /* flag, or-ed in: never dispatch to the large-M kernel mvp_gemm_pp (A/B measurements, tests of the tile kernels) */
 #define MVP_GEMM_STREAMK (-1)
+#define MVP_PAIR_SEPARATE 0
+#define MVP_PAIR_A_ILV32 1
+#define MVP_PAIR_W_ILV32 2
+#define MVP_PAIR_ILV32 3
 int mvp_gemm_bias_act_res(const mvp_gemm_args*, void* stream);
+/* The large-M bf16x3 kernel (csrc/gemm_pp.hip): 256x256 output tiles, one 8-wave workgroup per CU, LDS-DMA prefetch kept in flight
+ * across raw barriers with counted vmcnt, the two wave groups of a SIMD alternating between MFMA clusters and loads.  Same contract,
+ * same epilogue and — same accumulation order — the same bits as the tile kernels; plain linear GEMMs only (no conv, no split-K),
+ * K % 32 == 0, K >= 64.  mvp_gemm_bias_act_res dispatches to it by itself when M is large enough (see the rule in gemm.hip);
+ * this entry point forces it (benchmarks, tests).  Replaces the same nn.Linear call sites (ibot_transformers.py:95-106,124-145). */
+int mvp_gemm_pp(const mvp_gemm_args*, void* stream);
 int64_t mvp_gemm_splitk_workspace_bytes(int M, int N, int splits);
 int64_t mvp_gemm_streamk_workspace_bytes(void);
 int mvp_gemm_streamk(const mvp_gemm_args*, void* stream);  /* what mvp_gemm_bias_act_res dispatches to for splitk == MVP_GEMM_STREAMK */

@@ -1,0 +1,202 @@
+// Shared pieces of the MFMA GEMM kernels (gemm.hip, gemm_pp.hip): the erf-GELU, the XCD-region tile order and the fused
+// LDS-staged epilogue.  Header-only, force-inlined: each kernel keeps its own main loop and calls gemm_epilogue() once its
+// accumulators are final and every wave is done with the staging buffers (the caller's barrier).
+#pragma once
+#include "mvp_common.h"
+
+namespace {
+
+// Branch-free erf GELU: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one
+// v_rcp.  (ocml erff measured ~17 us of VALU on the fc1 epilogue.)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = __expf(-ax * ax);
+  const float erf_abs = 1.0f - poly * e;
+  const float erfv = copysignf(erf_abs, x);
+  return 0.5f * x * (1.0f + erfv);
+}
+
+// Logical tile index -> (tm, tn), XCD-region-major.  xcd_remap() hands each XCD one contiguous slice of the logical
+// index space; here that space is enumerated region by region, the output being cut into XR x XC = 8 rectangles
+// chosen to minimise what one XCD must pull through its L2: rows(A)/XR + rows(W)/XC; when a slice needs more than
+// one round of resident workgroups, near-ties go to more column cuts (the smaller W share then stays L2-resident
+// across the rounds).  Inside a region tiles run row-major.
+// With plain row-major enumeration every XCD streamed ALL of W: fc1 fetched 164 MB from the memory side for 19 MB
+// of operands at 26 % L2 misses (profiles/r01_pmc_*).  Uneven divisions only shift a few tiles across slice
+// borders; the map stays a bijection.
+__device__ __forceinline__ void region_tile(int L, int TM, int TN, int M, int N, bool multi_round, int& tm, int& tn) {
+  int XR = 1;
+  long best = (long)M * 8 + N;  // 8 * (M / XR + N * XR / 8)
+#pragma unroll
+  for (int c = 2; c <= 8; c <<= 1) {
+    const long cost = (long)M * 8 / c + (long)N * c;
+    if (cost + (multi_round ? cost / 16 : 0) < best) { best = cost; XR = c; }
+  }
+  const int XC = 8 / XR;
+  for (int r = 0; r < 8; ++r) {
+    const int xr = r / XC, xc = r - xr * XC;
+    const int r0 = xr * TM / XR, r1 = (xr + 1) * TM / XR, c0 = xc * TN / XC, c1 = (xc + 1) * TN / XC;
+    const int w = c1 - c0, sz = (r1 - r0) * w;
+    if (L < sz) {
+      const int q = L / w;
+      tm = r0 + q;
+      tn = c0 + (L - q * w);
+      return;
+    }
+    L -= sz;
+  }
+  tm = TM - 1; tn = TN - 1;  // unreachable: the regions partition TM x TN
+}
+
+// Fused epilogue.  acc[i][j] = 16x16 accumulator of n-fragment i, m-fragment j of this wave's WM x WN output tile (MFMA issued
+// "swapped": a lane's 4 registers are 4 consecutive output columns of row lane & 15).  smem = the kernel's dynamic LDS (>= NW * 32 *
+// (WN + 4) * 4 bytes), free for reuse.  (m0, n0) = the workgroup's tile origin, (wm0, wn0) = this wave's offset inside it.
+template <int NT, int MT, int WN, bool EXT>
+__device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
+                                              const int m0, const int n0, const int wm0, const int wn0) {
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  // EXT = false compiles the ReLU-gate / second-residual / post-residual-ReLU features out of the
+  // hot backbone instantiations (they cost ~2-3 % there, measured A/B in one process).
+  const uint8_t* x_relu_mask = EXT ? p.relu_mask : nullptr;
+  uint8_t* x_out_mask = EXT ? p.out_mask : nullptr;
+  const float* x_residual2 = EXT ? p.residual2 : nullptr;
+  const mvp_bf16* x_res_hi = EXT ? p.residual_hi : nullptr;
+  const int x_act_after = EXT ? p.act_after_res : 0;
+  const int x_mask_mode = EXT ? p.mask_mode : 0;
+  // Per-wave private scratch [32 rows][WN + 4] fp32; the trailing barrier of the main loop has
+  // retired every read of the staging buffers, so they can be reused.
+  constexpr int EPW = WN + 4;                 // padded row, floats (conflict-free b128 write/read)
+  constexpr int EP_BYTES = 32 * EPW * 4;      // per wave
+  constexpr int LPR = WN / 4;                 // lanes per output row (16 or 8)
+  constexpr int RPI = 64 / LPR;               // rows per wave-instruction (4 or 8)
+  float* ep = (float*)(smem + wave * EP_BYTES);
+  const int er = lane / LPR, ec = (lane % LPR) * 4;
+  const int ncol = n0 + wn0 + ec;
+  const bool vec_ok = ((p.N & 3) == 0) && (ncol + 3 < p.N);
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ncol + e < p.N) bias4[e] = p.bias[ncol + e];
+  }
+
+#pragma unroll
+  for (int h = 0; h < MT / 2; ++h) {
+    // phase 1: accumulators -> LDS (lane: row frow of m-tile, cols i*16 + 4*fq ..)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        *(f32x4_t*)(ep + (jj * 16 + frow) * EPW + i * 16 + fq * 4) = acc[i][h * 2 + jj];
+    // phase 2: row-contiguous read-back, fused bias / activation / residual, full-line stores
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int lr = it * RPI + er;
+      const int m = m0 + wm0 + h * 32 + lr;
+      const f32x4_t a4 = *(const f32x4_t*)(ep + lr * EPW + ec);
+      if (m >= p.M || ncol >= p.N) continue;
+      int orow = m;
+      if (p.row_group > 0) {
+        const int gidx = m / p.row_group;
+        orow = gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
+      }
+      const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : orow;
+      float v[4] = {a4[0] + bias4[0], a4[1] + bias4[1], a4[2] + bias4[2], a4[3] + bias4[3]};
+      if (p.act == MVP_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (p.act == MVP_ACT_RELU && !x_act_after) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      auto write_mask = [&]() {  // forward: remember which outputs the ReLU kept (its backward gate)
+        uint8_t* mo = x_out_mask + (size_t)orow * p.ldm + ncol;
+        if (vec_ok && ((p.ldm & 3) == 0)) {
+          *(uint32_t*)mo = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 0x100u : 0u) | (v[2] > 0.f ? 0x10000u : 0u) | (v[3] > 0.f ? 0x1000000u : 0u);
+        } else {
+          for (int e = 0; e < 4; ++e) if (ncol + e < p.N) mo[e] = v[e] > 0.f ? 1 : 0;
+        }
+      };
+      if (x_out_mask && !x_act_after) write_mask();
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (x_relu_mask) {  // backward of ReLU: gate by the saved byte mask
+        const uint8_t* mp = x_relu_mask + (size_t)orow * p.ldm + ncol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] = (ncol + e < p.N && mp[e]) ? 1.f : 0.f;
+        if (x_mask_mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= keep[e];
+        }
+      }
+      if (p.residual) {
+        const float* rp = p.residual + (size_t)rrow * p.ldr + ncol;
+        if (vec_ok && ((p.ldr & 3) == 0)) {
+          const float4 r = *(const float4*)rp;
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        } else {
+          for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
+        }
+      }
+      if (x_res_hi) {  // residual kept only as a bf16 pair (ResNet identities: no fp32 copy of every block output)
+        const size_t ro = (size_t)rrow * p.ldr + ncol;
+        if (vec_ok && ((p.ldr & 3) == 0)) {
+          const u32x2_t h2 = *(const u32x2_t*)(x_res_hi + ro);
+          const u32x2_t l2 = p.residual_lo ? *(const u32x2_t*)(p.residual_lo + ro) : u32x2_t{0u, 0u};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t hw = h2[e >> 1], lw = l2[e >> 1];
+            v[e] += __builtin_bit_cast(float, (e & 1) ? (hw & 0xffff0000u) : (hw << 16)) +
+                    __builtin_bit_cast(float, (e & 1) ? (lw & 0xffff0000u) : (lw << 16));
+          }
+        } else {
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < p.N) v[e] += bf2f(x_res_hi[ro + e]) + (p.residual_lo ? bf2f(p.residual_lo[ro + e]) : 0.f);
+        }
+      }
+      if (x_residual2) {
+        const float* rp = x_residual2 + (size_t)orow * p.ldr + ncol;
+        for (int e = 0; e < 4; ++e) if (ncol + e < p.N) v[e] += rp[e];
+      }
+      if (p.act == MVP_ACT_RELU && x_act_after) {  // ResNet bottleneck: relu(conv3(x) + identity)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        if (x_out_mask) write_mask();  // gate of the post-residual ReLU (pre-activation fusion blocks)
+      }
+      if (p.out_f32) {
+        float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
+        if (vec_ok && ((p.ldo & 3) == 0)) {
+          *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int e = 0; e < 4; ++e) if (ncol + e < p.N) op[e] = v[e];
+        }
+      }
+      if (p.out_hi) {
+        if (x_mask_mode == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= keep[e];  // (out_f32 above stayed un-gated)
+        }
+        uint32_t h01, l01, h23, l23;
+        split2_bf16(v[0], v[1], h01, l01);
+        split2_bf16(v[2], v[3], h23, l23);
+        const size_t o = (size_t)orow * p.ldob + ncol;
+        if (vec_ok && ((p.ldob & 3) == 0)) {
+          *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
+          if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{l01, l23};
+        } else {
+          const uint16_t hh[4] = {(uint16_t)h01, (uint16_t)(h01 >> 16), (uint16_t)h23, (uint16_t)(h23 >> 16)};
+          const uint16_t ll[4] = {(uint16_t)l01, (uint16_t)(l01 >> 16), (uint16_t)l23, (uint16_t)(l23 >> 16)};
+          for (int e = 0; e < 4; ++e)
+            if (ncol + e < p.N) {
+              p.out_hi[o + e] = hh[e];
+              if (p.out_lo) p.out_lo[o + e] = ll[e];
+            }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace

@@ -1,0 +1,337 @@
+// bf16x3 MFMA GEMM for large M on gfx950: 256x256 output tile, 8 waves, one workgroup per CU, "ping-pong" main loop.
+//
+//   Y[M,N] = act(A[M,K] · W[N,K]ᵀ + bias) + residual          (same contract and epilogue as gemm.hip)
+//
+// Why a second kernel.  gemm.hip's loop (one LDS stage, vmcnt(0) + barrier per k-tile, 2-5 co-resident workgroups) tops out at
+// 24-34 % MFMA-pipe utilisation: every LDS-DMA piece costs its SIMD ~5 MFMAs of issue time and a 128x128 bf16x3 tile issues only 6
+// MFMAs per piece.  This kernel follows cdna_hip_programming.md §5 ("what does break it"): ~1 workgroup per CU whose LDS-DMA
+// prefetch stays in flight ACROSS barriers — all LDS in one array, counted s_waitcnt vmcnt(N) (never 0 in the loop), raw
+// s_barrier — on a tile with 12 MFMAs per piece:
+//   * tile 256x256, k-step 32; per k-step a CU stages 64 KB (A 256 rows + W 256 rows, hi and lo) and issues 768 MFMAs.
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128x64 (acc[4][8] 16x16 accumulators = 128 registers).
+//   * the two wave groups (wr = 0 / 1, one wave of each per SIMD) run the SAME stream staggered by one barrier interval:
+//     while one wave of a SIMD issues its 48-MFMA cluster (s_setprio 1) its partner reads fragments from LDS and issues
+//     LDS-DMA; every barrier swaps the roles.  MFMA issue, LDS reads and DMA issue therefore overlap inside each SIMD.
+//   * each k-step has two phases: P1 = rows [0,64) of the wave tile x all 64 columns (reads 8 A + 8 W fragments), P2 = rows
+//     [64,128) (reads 8 A fragments, W fragments stay in registers).  So the A half "HA0" and the whole W tile "HB" of a
+//     k-step are dead after P1 and HA1 after P2, and with two LDS buffers (by k-step parity) the staging runs 3 phases ahead:
+//       P2(t)   issues HA0(t+2) x2, HB(t+2) x4   (per wave; both slots were last read in P1(t))
+//       P1(t+1) issues HA1(t+2) x2               (slot last read in P2(t))
+//     so the read interval with 16 fragment reads issues 2 pieces and the one with 8 reads issues 6, and every piece has ~1.5
+//     k-steps (2.5-3 us) to land — the A operand streams from HBM (~2 us under load; the first version staged HA only one k-step
+//     ahead and measured latency-bound: 2.09 us per k-step against 1.64 with the DMA ablated).  The counted wait is vmcnt(8) at the
+//     end of every read interval: all but the wave's 8 youngest pieces have landed, which covers exactly what the NEXT phase reads
+//     (end of P2(t): HA0(t+1), HB(t+1); end of P1(t): HA1(t)).  The wait precedes a barrier and the reads of that data come after
+//     it (RAW); every ds_read is retired by lgkmcnt(0) BEFORE the barrier that ends its interval, so a DMA issued after that
+//     barrier cannot overtake it (WAR).
+//
+// Operand layouts (templates ILVA / ILVW, chosen per operand by mvp_gemm_args.pair_layout):
+//   false: separate hi / lo arrays, K contiguous (what the rest of the library produces).  A 32-deep k-step of one array is
+//     a 64-byte row segment (half a cache line per LDS-DMA row); LDS image per operand = [hi: 256 rows x 64 B][lo: same],
+//     16-row pieces, swizzle chunk ^= {0,2,3,1}[(row >> 2) & 3] (gemm.hip's BK = 32 image).
+//   true: ONE array for the operand, hi | lo interleaved per 32-deep k block: row = [k/32][hi 32 | lo 32] bf16, so the k-step
+//     of a row is one whole 128-byte line; LDS image [256 rows x 128 B], 8-row pieces, swizzle chunk ^= row & 7 (gemm.hip's
+//     BK = 64 image with "k half 0 / 1" = hi / lo).
+//
+// The accumulation order per output element is gemm.hip's: per 32-deep k-step lo·hi, hi·lo, hi·hi, k ascending — the results are
+// bit-identical to the tile kernels'.
+#include "gemm_epilogue.h"
+
+#ifndef MVP_PP_ABLATE
+#define MVP_PP_ABLATE 0  // diagnostic builds (tools/pp_bench.py): 1 = no MFMA, 2 = no LDS-DMA in the loop, 3 = no fragment reads
+#endif
+// MVP_PP_STAMP 1 (diagnostic build only): s_memtime stamps around the five segments of every phase (issue of reads + LDS-DMA, the
+// counted waits, barrier 1, the MFMA cluster, barrier 2), summed per phase type in SGPRs by waves 0 and 4 of every workgroup and
+// written to splitk_ws as uint64 [workgroup][group][10] at the end (cdna_hip_programming.md §7, in-kernel stamps).
+#ifndef MVP_PP_STAMP
+#define MVP_PP_STAMP 0
+#endif
+#if MVP_PP_STAMP
+#define PP_STAMP(v) const uint64_t v = __builtin_amdgcn_s_memtime()
+#define PP_ACC(ph) \
+  do { tacc[ph * 5 + 0] += s_x - s_e; tacc[ph * 5 + 1] += s_b - s_x; tacc[ph * 5 + 2] += s_c - s_b; tacc[ph * 5 + 3] += s_d - s_c; tacc[ph * 5 + 4] += s_f - s_d; s_e = s_f; } while (0)
+#else
+#define PP_STAMP(v)
+#define PP_ACC(ph)
+#endif
+
+namespace {
+
+template <int V>
+struct ic { static constexpr int value = V; };
+
+constexpr int PP_TILE_B = 256 * 128;     // bytes per operand tile per k-step (hi + lo)
+constexpr int PP_BUF_B = 2 * PP_TILE_B;  // A tile + W tile of one k-step
+constexpr int PP_SMEM = 2 * PP_BUF_B;    // two k-step buffers = 128 KiB
+
+template <bool ILVA, bool ILVW, bool EXT>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MT = 8, NT = 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform (SGPR): LDS-DMA destinations, resource choice
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  int tm, tn;
+  region_tile(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.M, p.N, tiles_m * tiles_n > 256, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm0 = wr * WM, wn0 = wc * WN;
+  const int nk = p.K >> 5;
+
+  // ---------------------------------------------------------------- staging geometry (per operand: A and W may differ in layout)
+  // piece = one wave-instruction of LDS-DMA = 1 KiB of the LDS image: 8 rows x 128 B (interleaved) or 16 rows x 64 B (separate arrays).
+  auto prow_of = [&](bool ilv) { return ilv ? (lane >> 3) : (lane >> 2); };  // row inside the piece
+  auto csrc_of = [&](bool ilv) {                                             // swizzled source chunk, bytes
+    const int pr = prow_of(ilv);
+    const int csw = ilv ? (pr & 7) : ((0x1320 >> (((pr >> 2) & 3) * 4)) & 3);
+    return (((ilv ? (lane & 7) : (lane & 3)) ^ csw)) << 4;
+  };
+  constexpr int KSTEP_A = ILVA ? 128 : 64, KSTEP_W = ILVW ? 128 : 64;  // bytes of one k-step inside a source row
+  // A pieces of this wave: list index i = 2 * wave + e (e = 0, 1) into the 16 pieces of a half (HA0; HA1 = the next 64 rows)
+  int qa[2];  // piece index inside the operand tile image (HA0 piece; HA1 = + 64 rows)
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = 2 * wave + e;
+    qa[e] = ILVA ? ((i < 8) ? i : i + 8) : ((i & 3) + ((i >> 2) & 1) * 8 + (i >> 3) * 16);
+  }
+  constexpr int HALF_STEP = ILVA ? 8 : 4;  // pieces per 64 rows of A
+  // W pieces of this wave: 4 consecutive pieces
+  auto piece_row0 = [&](bool ilv, int q) { return ilv ? q * 8 : (q & 15) * 16; };  // first tile row of piece q
+  auto piece_lo = [&](bool ilv, int q) { return ilv ? 0 : (q >> 4); };             // 1: the piece belongs to the lo array (separate arrays)
+
+  const size_t a_base = (size_t)m0 * p.lda, w_base = (size_t)n0 * p.ldw;
+  const mvp_bf16* const pa_hi = p.a_hi + a_base;
+  const mvp_bf16* const pa_lo = (ILVA ? p.a_hi : p.a_lo) + a_base;
+  const mvp_bf16* const pw_hi = p.w_hi + w_base;
+  const mvp_bf16* const pw_lo = (ILVW ? p.w_hi : p.w_lo) + w_base;
+  int a_voff[4], w_voff[4];  // per-lane byte offsets of this wave's pieces: [HA0 e0, HA0 e1, HA1 e0, HA1 e1], [HB 0..3]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = qa[e & 1] + (e >> 1) * HALF_STEP;
+    const int row = min(piece_row0(ILVA, q) + prow_of(ILVA), p.M - 1 - m0);  // rows past M re-read the last row (never stored)
+    a_voff[e] = row * p.lda * 2 + csrc_of(ILVA);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = 4 * wave + e;
+    const int row = min(piece_row0(ILVW, q) + prow_of(ILVW), p.N - 1 - n0);
+    w_voff[e] = row * p.ldw * 2 + csrc_of(ILVW);
+  }
+
+  auto stage_a = [&](int par, int kt, int half) {  // this wave's two pieces of HA<half> of k-step kt
+#if MVP_PP_ABLATE != 2
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int q = qa[e] + half * HALF_STEP;
+      lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, 0x7fffff00u, smem + par * PP_BUF_B + q * 1024, a_voff[half * 2 + e], kt * KSTEP_A);
+    }
+#endif
+  };
+  auto stage_w = [&](int par, int kt) {  // this wave's four pieces of HB of k-step kt
+#if MVP_PP_ABLATE != 2
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = 4 * wave + e;
+      lds_dma16(piece_lo(ILVW, q) ? pw_lo : pw_hi, 0x7fffff00u, smem + par * PP_BUF_B + PP_TILE_B + q * 1024, w_voff[e], kt * KSTEP_W);
+    }
+#endif
+  };
+
+  // ---------------------------------------------------------------- fragment reads
+  const int frow = lane & 15, fq = lane >> 4;
+  // interleaved: byte = row * 128 + (((h * 4 + fq) ^ (row & 7)) << 4);   separate: h * 16 KiB + row * 64 + ((fq ^ sw(row)) << 4)
+  auto foff = [&](bool ilv, int h) {
+    const int fsw = ilv ? (frow & 7) : ((0x1320 >> (((frow >> 2) & 3) * 4)) & 3);
+    return ilv ? (frow * 128 + (((h * 4 + fq) ^ fsw) << 4)) : (h * 16384 + frow * 64 + ((fq ^ fsw) << 4));
+  };
+  const int fa_hi = foff(ILVA, 0), fa_lo = foff(ILVA, 1), fw_hi = foff(ILVW, 0), fw_lo = foff(ILVW, 1);
+  constexpr int AROWB = ILVA ? 128 : 64, WROWB = ILVW ? 128 : 64;  // bytes per LDS row
+  const char* const a_rd = smem + wm0 * AROWB;
+  const char* const w_rd = smem + PP_TILE_B + wn0 * WROWB;
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t a_hi[4], a_lo[4], w_hi[4], w_lo[4];
+
+  auto read_a = [&](int par, int half) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const char* r = a_rd + par * PP_BUF_B + (half * 4 + j) * 16 * AROWB;
+      a_hi[j] = *(const bf16x8_t*)(r + fa_hi);
+      a_lo[j] = *(const bf16x8_t*)(r + fa_lo);
+    }
+  };
+  auto read_w = [&](int par) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const char* r = w_rd + par * PP_BUF_B + i * 16 * WROWB;
+      w_hi[i] = *(const bf16x8_t*)(r + fw_hi);
+      w_lo[i] = *(const bf16x8_t*)(r + fw_lo);
+    }
+  };
+  auto mma = [&](const int half) {  // 48 MFMAs: 4 n-fragments x 4 m-fragments x (lo·hi, hi·lo, hi·hi); `half` is a literal at every call
+#if MVP_PP_ABLATE == 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { asm volatile("" ::"v"(a_hi[j])); asm volatile("" ::"v"(a_lo[j])); asm volatile("" ::"v"(w_hi[j])); asm volatile("" ::"v"(w_lo[j])); }
+#else
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4_t c = acc[i][half * 4 + j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_hi[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_lo[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_hi[j], c, 0, 0, 0);
+        acc[i][half * 4 + j] = c;
+      }
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
+  // ---------------------------------------------------------------- prologue: HA0(0), HB(0), HA1(0), then what "P2(-1)" would issue
+  stage_a(0, 0, 0);
+  stage_w(0, 0);
+  stage_a(0, 0, 1);
+  if (nk > 1) {
+    stage_a(1, 1, 0);
+    stage_w(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA0(0), HB(0) landed (this wave's pieces); HA1(0) x2, HA0(1) x2, HB(1) x4 in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
+
+#if MVP_PP_STAMP
+  uint64_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t s_e = __builtin_amdgcn_s_memtime(), s_x = 0;
+#endif
+  auto kstep = [&](int t, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    // ---- P1, read interval: fragments of rows [0,64) + all W fragments; stage HA1(t+1)
+#if MVP_PP_ABLATE != 3
+    read_w(par);
+    read_a(par, 0);
+#endif
+    if (t + 1 < nk) {
+      stage_a(par ^ 1, t + 1, 1);
+      {
+        PP_STAMP(s_x0);
+#if MVP_PP_STAMP
+        s_x = s_x0;
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA1(t) landed; HA0(t+1) x2, HB(t+1) x4, HA1(t+1) x2 stay in flight
+    } else {
+      {
+        PP_STAMP(s_x0);
+#if MVP_PP_STAMP
+        s_x = s_x0;
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every fragment read is retired before the barrier (the builtin, so that hipcc counts it)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      PP_STAMP(s_b);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(s_c);
+      mma(0);
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(s_d);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(s_f);
+      PP_ACC(0);
+    }
+    // ---- P2, read interval: fragments of rows [64,128); stage HA0(t+2), HB(t+2)
+#if MVP_PP_ABLATE != 3
+    read_a(par, 1);
+#endif
+    if (t + 2 < nk) {
+      stage_a(par, t + 2, 0);
+      stage_w(par, t + 2);
+    }
+    {
+      PP_STAMP(s_x0);
+#if MVP_PP_STAMP
+      s_x = s_x0;
+#endif
+    }
+    if (t + 2 < nk) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA0(t+1), HB(t+1) landed; HA1(t+1) x2 and this phase's 6 stay in flight
+    } else if (t + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // HA1(t+1) x2 may stay in flight
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): every fragment read is retired before the barrier (the builtin, so that hipcc counts it)
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      PP_STAMP(s_b);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(s_c);
+      mma(1);
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(s_d);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(s_f);
+      PP_ACC(1);
+    }
+  };
+
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    kstep(t, ic<0>{});
+    kstep(t + 1, ic<1>{});
+  }
+  if (t < nk) kstep(t, ic<0>{});
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last interval
+#if MVP_PP_STAMP
+  if (p.splitk_ws && wc == 0 && lane == 0) {
+    uint64_t* dbg = (uint64_t*)p.splitk_ws + ((size_t)blockIdx.x * 2 + wr) * 10;
+    for (int c = 0; c < 10; ++c) dbg[c] = tacc[c];
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // every wave is done with the staging buffers -> the epilogue reuses them
+
+  gemm_epilogue<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0);
+}
+
+template <bool ILVA, bool ILVW>
+int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
+  static int configured = [] {
+    int e = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+    return e;
+  }();
+  if (configured != 0) return MVP_ELAUNCH;
+  const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi;
+  if (ext)
+    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
+  else
+    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, false>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+}  // namespace
+
+extern "C" int mvp_gemm_pp(const mvp_gemm_args* a, void* stream) {
+  if (!a || !a->a_hi || !a->w_hi) return MVP_EINVAL;
+  if (a->pair_layout < 0 || a->pair_layout > (MVP_PAIR_A_ILV32 | MVP_PAIR_W_ILV32)) return MVP_EINVAL;
+  const bool ilva = a->pair_layout & MVP_PAIR_A_ILV32, ilvw = a->pair_layout & MVP_PAIR_W_ILV32;
+  if ((!ilva && !a->a_lo) || (!ilvw && !a->w_lo)) return MVP_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K < 64 || (a->K & 31) || a->conv || a->splitk > 1) return MVP_EINVAL;
+  if ((a->lda & 7) || (a->ldw & 7) || a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
+  if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
+  // 32-bit per-lane byte offsets: 256 tile rows of the widest supported row must stay below 2 GiB
+  if ((int64_t)256 * a->lda * 2 >= 0x7fffff00ll || (int64_t)256 * a->ldw * 2 >= 0x7fffff00ll) return MVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (ilva) return ilvw ? launch_pp<true, true>(a, st) : launch_pp<true, false>(a, st);
+  return ilvw ? launch_pp<false, true>(a, st) : launch_pp<false, false>(a, st);
+}

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 from mvp import backbone as bb
 from mvp import functional as MF
+from mvp import pipeline
 
 
 class MoCoV3(bb.ViTBackbone):
@@ -48,4 +49,6 @@ class MoCoV3(bb.ViTBackbone):
         if len(self.multilayers) == 1 and self.return_cls:
             return self.engine().forward_tokens(images, self.multilayers[0] + 1)[:, 0]
         taps = self._extract(images)
+        if isinstance(taps, bb.TapGroups):  # several batches stacked into one forward (mvp/pipeline.py): one result per batch
+            return pipeline.GroupedFeatures((t[0] if len(t) == 1 else t) for t in taps)
         return taps[0] if len(taps) == 1 else taps

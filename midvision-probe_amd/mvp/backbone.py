@@ -13,8 +13,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import lib
-from .vit import TapOutputs, ViTEngine, parse_precision
+from . import lib, pipeline
+from .vit import TapGroups, TapOutputs, ViTEngine, parse_precision
 
 
 def default_precision() -> str:
@@ -165,6 +165,12 @@ class ViTBackbone(nn.Module):
     supports_pipelining = True  # per-slot buffers, tap-BN running-statistics updates deferred to the consumer (mvp/pipeline.py)
     graph_safe = True  # a pipelined forward launches only this library's kernels on fixed buffers: it can be captured in a hipGraph
 
+    def supports_grouping(self) -> bool:
+        """True when the pipeline may stack several batches into ONE forward (mvp/pipeline.py, ``group``): the dense / multilayer
+        paths, whose ``forward`` ends in ``_finish(_extract(images))``.  The single-tap ``return_cls`` shortcuts return a bare
+        token tensor and stay one batch per forward."""
+        return not (len(self.multilayers) == 1 and getattr(self, "return_cls", False))
+
     def _setup_taps(self, feat_dim, layer, return_multilayer, add_norm, num_layers):
         multilayers = multilayer_indices(num_layers)
         if return_multilayer:
@@ -214,13 +220,16 @@ class ViTBackbone(nn.Module):
         bns, mode = self._tap_bn()
         with torch.no_grad():
             taps = eng.forward_taps(images, self.multilayers, bn=bns, bn_mode=mode, tap_input_of_block=self.tap_input_of_block,
-                                    want_cls=want_cls or self.output in ("cls", "dense-cls"))
+                                    want_cls=want_cls or self.output in ("cls", "dense-cls"), groups=pipeline.current_groups())
             # (num_batches_tracked is incremented by the tap kernel's statistics pass: no extra launch)
         return taps
 
     def _finish(self, taps: TapOutputs):
         """tokens_to_output (evals/models/utils.py:105-124) per tap.  'dense' is the kernel's own output; 'cls' is the
-        (tap-normalised) CLS token the tap kernel emits next to the map; 'gap' / 'dense-cls' are shape glue on those."""
+        (tap-normalised) CLS token the tap kernel emits next to the map; 'gap' / 'dense-cls' are shape glue on those.
+        A grouped forward (TapGroups: one TapOutputs per batch) is finished batch by batch -> pipeline.GroupedFeatures."""
+        if isinstance(taps, TapGroups):
+            return pipeline.GroupedFeatures(self._finish(t) for t in taps)
         if self.output == "dense":
             outs = list(taps)
         elif self.output == "cls":

@@ -20,6 +20,8 @@ PREC_BF16 = 1
 PREC_BF16X3 = 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BICUBIC = 0, 1, 2
+PAIR_SEPARATE, PAIR_A_ILV32, PAIR_W_ILV32 = 0, 1, 2  # mvp_gemm_args.pair_layout (bit flags)
+TILES_SHARED, TILES_NO_PP = 1, 2
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -52,7 +54,7 @@ class GemmArgs(C.Structure):
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
                 ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64),
-                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i)]
+                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i), ("pair_layout", _i)]
 
 
 class LayerNormArgs(C.Structure):
@@ -234,6 +236,7 @@ SYMBOLS = {
     "mvp_im2col_nchw": Im2colArgs,
     "mvp_maxpool_cl": MaxpoolClArgs,
     "mvp_stem7x7_pool": StemArgs,
+    "mvp_gemm_pp": GemmArgs,
     "mvp_gemm_tn_workspace_bytes": None,
     "mvp_gemm_tn_conv": GemmTnArgs,
 }

@@ -44,6 +44,11 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
     if splitk > 1:
         bn = 128 if N >= 1024 else 64
         return f"128, {bn}, 64, 3, 1, splitk" if precision == PREC_BF16X3 else f"128, {bn}, 64, 1, 2, splitk"
+    if precision == PREC_BF16X3 and K % 32 == 0 and K >= 64 and not (N <= 256 and K >= 2048) and os.environ.get("MVP_GEMM_PP", "") != "0":
+        t256 = ((M + 255) // 256) * ((N + 255) // 256)  # pp_takes() of csrc/gemm.hip: the large-M ping-pong kernel
+        rounds = (t256 + 255) // 256
+        if os.environ.get("MVP_GEMM_PP") == "1" or (t256 >= 96 if tile_policy == 1 else (t256 >= 128 if K >= 2048 else t256 >= 200 and (t256 * 5 >= rounds * 1024 or t256 >= 1024))):
+            return "pp 256, 256, 32, 3"
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     if precision == PREC_BF16X3:
         if N <= 256 and K >= 2048:
@@ -81,6 +86,17 @@ def split_bf16(src: torch.Tensor, precision: int = PREC_BF16X3) -> Pair:
     a = lib.SplitArgs(lib.ptr(src), lib.ptr(hi), lib.ptr(lo), src.numel())
     lib.call("mvp_split_bf16", a)
     return hi, lo
+
+
+def interleave_pair(pair: Pair) -> Optional[torch.Tensor]:
+    """(hi, lo) [R, K] -> ONE [R, 2K] bf16 array, hi | lo interleaved per 32-deep k block (MVP_PAIR_*_ILV32, include/mvp_hip.h): the
+    operand layout in which a 32-deep k-step of a row is one whole 128-byte line.  Used for the frozen weights (built once at load; the
+    large-M GEMM kernel reads them 2-3.5 % faster than the separate arrays).  None when K % 32 != 0 or the pair has no lo part."""
+    hi, lo = pair
+    if lo is None or hi.dim() != 2 or hi.shape[1] % 32:
+        return None
+    R, K = hi.shape
+    return torch.stack((hi.view(R, K // 32, 32), lo.view(R, K // 32, 32)), dim=2).reshape(R, 2 * K).contiguous()
 
 
 def patch_gather(images: torch.Tensor, out: Pair, P: int, gh: int, gw: int, pad_top: int, pad_left: int) -> None:
@@ -145,10 +161,12 @@ def _splitk_workspace(M: int, N: int, S: int, device) -> torch.Tensor:
 def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, out_f32=None, out: Optional[Pair] = None,
          act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
          row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0,
-         splitk: Optional[int] = None, residual_pair: Optional[Pair] = None, streamk: Optional[bool] = None) -> None:
+         splitk: Optional[int] = None, residual_pair: Optional[Pair] = None, streamk: Optional[bool] = None,
+         w_ilv: Optional[torch.Tensor] = None) -> None:
     """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off.
     residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``.
-    streamk: None = automatic (streamk_auto), True / False force the stream-K kernel on / off."""
+    streamk: None = automatic (streamk_auto), True / False force the stream-K kernel on / off.
+    w_ilv: the same weights as ``interleave_pair(w)``; handed to the large-M kernel when the dispatch rule picks it."""
     o_hi, o_lo = out if out is not None else (None, None)
     args = lib.GemmArgs(
         lib.ptr(a[0]), lib.ptr(a[1]), lib.ptr(w[0]), lib.ptr(w[1]), lib.ptr(bias), lib.ptr(residual),
@@ -173,6 +191,9 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     if S > 1:
         ws = _splitk_workspace(M, N, S, a[0].device)
         args.splitk, args.splitk_ws, args.splitk_ws_bytes = S, lib.ptr(ws), ws.numel()
+    tile = gemm_tile(M, N, K, precision, S, args.tile_policy) if (w_ilv is not None or _TRACE is not None) else ""
+    if w_ilv is not None and plain and not use_sk and S <= 1 and tile.startswith("pp ") and ldw is None:
+        args.w_hi, args.w_lo, args.ldw, args.pair_layout = lib.ptr(w_ilv), None, 2 * K, lib.PAIR_W_ILV32
     if _TRACE is None:
         lib.call("mvp_gemm_bias_act_res", args)
         return
@@ -180,7 +201,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     e0.record()
     lib.call("mvp_gemm_bias_act_res", args)
     e1.record()
-    _TRACE.append(("gemm", "streamk 128, 128, 64" if use_sk else gemm_tile(M, N, K, precision, S, args.tile_policy), precision, 2.0 * M * N * K, e0, e1))
+    _TRACE.append(("gemm", "streamk 128, 128, 64" if use_sk else tile, precision, 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,

@@ -17,6 +17,15 @@ state allocates nothing.  A slot is reused only after the trainer's stream has p
 (``submit`` makes the side stream wait for the trainer's stream).  Contract: the features ``next()`` returns are valid until
 ``depth`` further forwards have been submitted — consume them (probe forward + backward) before feeding the pipeline again, as
 ``pipelined_features`` does; ``.clone()`` anything that must live longer.
+
+Grouped forwards (round 3).  A forward may cover a GROUP of G consecutive batches: their images are stacked into one
+[G * B, 3, H, W] input and run through ONE chain of launches with M = G * B * N token rows — what the large-M GEMM kernel
+(csrc/gemm_pp.hip: 256x256 tiles, 92 % of the MFMA issue rate in its main loop) needs to fill 256 CUs: at B = 16, 224^2 a single
+batch has 3152 rows = 13 x 3 such tiles, six batches have 74 x 3.  Every kernel of the frozen forward is per row or per image
+except the tap BN, whose train-mode statistics belong to ONE batch (dino.py:185-191): the engine runs it per batch on that
+batch's rows, and its running-statistics updates are applied per batch, in batch order, when the batch is handed over.  Each batch
+therefore gets exactly the bits it would get alone (tests/test_gpu_pipeline.py); the probe steps still run one batch at a time, in
+order, as train_depth.py:99-143 does.
 """
 from __future__ import annotations
 
@@ -28,6 +37,7 @@ from typing import Iterable, Iterator, Tuple
 import torch
 
 _SLOT = 0  # slot of the forward being enqueued (host state; kernels are enqueued by one host thread)
+_GROUPS = 1  # batches stacked into the forward being enqueued
 _PIPELINED = False
 _SHARED = False  # >= 3 kernel chains side by side: the GEMMs pick the tiles meant for a shared chip (mvp_hip.h, MVP_TILES_SHARED)
 SHARED_TILES_FROM = 3
@@ -38,9 +48,19 @@ def current_slot() -> int:
     return _SLOT
 
 
+def current_groups() -> int:
+    """Number of equal batches stacked along dim 0 of the forward being enqueued (1 outside a grouped pipeline forward)."""
+    return _GROUPS
+
+
 def pipelined() -> bool:
     """True while a forward is being enqueued on a pipeline side stream."""
     return _PIPELINED
+
+
+class GroupedFeatures(list):
+    """Result of a grouped forward: the features of each batch of the group, in batch order (each entry is what ``model(images)``
+    returns for that batch alone)."""
 
 
 def tile_policy() -> int:
@@ -50,14 +70,14 @@ def tile_policy() -> int:
 
 
 @contextlib.contextmanager
-def _slot(i: int, chains: int = 2):
-    global _SLOT, _PIPELINED, _SHARED
-    prev = (_SLOT, _PIPELINED, _SHARED)
-    _SLOT, _PIPELINED, _SHARED = i, True, chains >= SHARED_TILES_FROM
+def _slot(i: int, chains: int = 2, groups: int = 1):
+    global _SLOT, _PIPELINED, _SHARED, _GROUPS
+    prev = (_SLOT, _PIPELINED, _SHARED, _GROUPS)
+    _SLOT, _PIPELINED, _SHARED, _GROUPS = i, True, chains >= SHARED_TILES_FROM, groups
     try:
         yield
     finally:
-        _SLOT, _PIPELINED, _SHARED = prev
+        _SLOT, _PIPELINED, _SHARED, _GROUPS = prev
 
 
 def publish() -> None:
@@ -68,14 +88,15 @@ def publish() -> None:
         torch.cuda.synchronize()
 
 
-_DEFERRED = []  # state updates registered by the forward being enqueued, applied by the consumer in batch order
+_DEFERRED = []  # (batch of the group, update) registered by the forward being enqueued, applied by the consumer in batch order
 
 
-def defer(fn) -> None:
+def defer(fn, group: int = 0) -> None:
     """Register an update of state shared by all forwards (the tap-BN running statistics and step counter: the only state a frozen
     forward mutates).  A pipelined forward must not apply it itself — forwards on different streams finish in any order — so
-    ``FeaturePipeline.next()`` runs it on the trainer's stream when the batch is handed over: batch order, no cross-stream event."""
-    _DEFERRED.append(fn)
+    ``FeaturePipeline.next()`` runs it on the trainer's stream when the batch is handed over: batch order, no cross-stream event.
+    ``group``: which batch of a grouped forward the update belongs to."""
+    _DEFERRED.append((group, fn))
 
 
 def _take_deferred():
@@ -107,14 +128,15 @@ def shared_tiles(on: bool = True):
         _SHARED = prev
 
 
-def default_depth(probe=None) -> int:
-    """Batches whose forward is submitted ahead of the probe step (= buffer slots) in the trainers and bench.py.  They run on
-    min(depth, 3) side streams.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).  Otherwise 4, except under a DPT
-    probe.  Measured on MI355X at B=16 (bench.py, img/s): linear probe at 224^2 — one chain 5440-5660; two chains 6380-6450; three
-    chains 6610 with the same tiles and 7150-7340 with the shared-chip tiles (tile_policy); four chains 6210-6340, five 6820-7030, six
-    6210-7120 (GPU_MAX_HW_QUEUES 8 / 16 change nothing).  Three chains with 4 / 5 / 6 slots — the next forward of a chain starts when
-    the chain's previous one ends, without waiting for that batch's probe step — 7400-7530 / 7390-7570 / 7550; 2 chains + 4 slots
-    6710-6800.  The DPT probe step (19 ms of chip-filling convolutions per batch) loses 739-748 -> 699-723 to a forward beside it."""
+def default_depth(probe=None, group: int = 1) -> int:
+    """Forwards submitted ahead of the probe step (= buffer slots) in the trainers and bench.py.  They run on min(depth, 3) side
+    streams.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).  Otherwise: 1 under a DPT probe; 2 for grouped
+    forwards (``group`` > 1: one group is being consumed batch by batch while the next one's forward runs); 4 single-batch forwards.
+    Measured on MI355X at B=16 (bench.py, img/s), single-batch forwards: linear probe at 224^2 — one chain 5440-5660; two chains
+    6380-6450; three chains 6610 with the same tiles and 7150-7340 with the shared-chip tiles (tile_policy); four chains 6210-6340, five
+    6820-7030, six 6210-7120 (GPU_MAX_HW_QUEUES 8 / 16 change nothing).  Three chains with 4 / 5 / 6 slots — the next forward of a chain
+    starts when the chain's previous one ends, without waiting for that batch's probe step — 7400-7530 / 7390-7570 / 7550; 2 chains + 4
+    slots 6710-6800.  The DPT probe step (19 ms of chip-filling convolutions per batch) loses 739-748 -> 699-723 to a forward beside it."""
     env = os.environ.get("MVP_INFLIGHT")
     if env is not None:
         return max(1, int(env))
@@ -124,7 +146,26 @@ def default_depth(probe=None) -> int:
         # several ranks rehearsing on ONE card (tests, bench.py over gloo): their queues oversubscribe the card's hardware
         # queues and the processes get time-sliced (measured: 150 ms per step instead of 3)
         return 1
-    return 4
+    return 2 if group > 1 else 4
+
+
+GROUP_ROWS = 19000  # token rows a grouped forward aims at: 6 batches of 16 x 197 = 18912 rows = 74 x {3, 9, 12} tiles of 256^2, 87 % of whole rounds of 256 CUs
+MAX_GROUP = 8
+
+
+def default_group(model, images: torch.Tensor, depth: int) -> int:
+    """Batches per grouped forward for batches shaped like ``images``.  MVP_PIPELINE_GROUP wins when set.  1 when the pipeline runs
+    inline (depth 1) or the backbone cannot group; else as many batches as bring one forward to about GROUP_ROWS token rows."""
+    env = os.environ.get("MVP_PIPELINE_GROUP")
+    ok = getattr(model, "supports_grouping", None)
+    if depth <= 1 or ok is None or not ok():
+        return 1
+    if env is not None:
+        return max(1, min(MAX_GROUP, int(env)))
+    P = int(getattr(model, "patch_size", 16))
+    B, H, W = images.shape[0], images.shape[-2], images.shape[-1]
+    rows = B * (1 + (-(-H // P)) * (-(-W // P)))
+    return max(1, min(MAX_GROUP, int(round(GROUP_ROWS / rows))))
 
 
 def _tensors(obj):
@@ -143,31 +184,43 @@ class FeaturePipeline:
     """``submit(images)`` enqueues ``model(images)`` on a side stream; ``next()`` returns the oldest submitted features on the
     caller's current stream (event wait, no host sync) after applying the forward's deferred state updates.  ``depth`` = forwards
     in flight; backbones without ``supports_pipelining`` run inline on the caller's stream, as does depth 1.
+    ``submit_group([images, ...])`` enqueues ONE forward over several equal-shaped batches (see the module docstring); ``next()``
+    still hands the batches over one at a time, in order.  ``group`` = batches per full group (1: single-batch forwards; None:
+    ``default_group`` at the first submit, what ``pipelined_features`` and bench.py ask for); ``free_slots()`` tells how many more
+    forwards may be submitted.
 
     ``graphs`` (default MVP_PIPELINE_GRAPHS != "0"): a ``graph_safe`` backbone's forward is captured once per (slot, input shape) in a
     hipGraph and replayed — one launch call instead of ~100, 1.4 ms of host time per step down to 0.4, so a busy host (data loading,
     logging) no longer starves the device.  The first forward of every slot runs eagerly (it allocates the slot's buffers and builds
     lazily cached operands) and is then captured; later ones replay; the input batch is copied into the graph's static buffer.
+    Of grouped forwards only FULL groups are captured (all slots at the pipeline's first submit, whatever that submit's size, so
+    that no capture falls into the run); a ragged last group runs eagerly.
     A graph is tied to the engine it was captured from (rebuilt weights invalidate it: new key, new capture)."""
 
-    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None):
+    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None, group: int = 1):
         """``run_ahead``: the host may be at most this many forwards ahead of the device (MVP_RUN_AHEAD, default 8; 0 = unbounded).
         The reference's loop syncs every step (``loss.item()``, train_depth.py:143); a loop that never syncs would otherwise queue
         hundreds of launches (and keep their argument buffers alive).  Throughput-neutral on MI355X (tools/micro/pipeline_probe.py,
         B=16, 300 steps, 2 in flight: 6526 img/s unbounded, 6565 with 8, 6584 with 3)."""
+        self._depth_arg = depth
         depth = default_depth() if depth is None else int(depth)
         if depth < 1:
             raise ValueError("depth must be >= 1")
         if not getattr(model, "supports_pipelining", False):
             depth = 1
         self.model, self.depth = model, depth
+        self.group = None if group is None else max(1, int(group))  # resolved at the first submit (needs the batch shape)
+        if self.depth == 1:
+            self.group = 1
         # (stream priorities do not help: the device offers only (0, -1), and high-priority side streams measured the same)
-        # ``depth`` batches are submitted ahead (one buffer slot each); they run on ``streams`` side streams = kernel chains side by side
+        # ``depth`` forwards are submitted ahead (one buffer slot each); they run on ``streams`` side streams = kernel chains side by side
         if streams is None:
             streams = int(os.environ.get("MVP_PIPELINE_STREAMS", str(MAX_STREAMS)))
+        self._streams_arg = int(streams)
         self.chains = max(1, min(depth, int(streams)))
         self.streams = [torch.cuda.Stream() for _ in range(self.chains)] if depth > 1 else []
-        self._queue = collections.deque()
+        self._queue = collections.deque()  # one entry per BATCH: (features, completion event of its forward, deferred updates)
+        self._open = collections.deque()   # per forward in flight: batches of it not yet handed over
         self._n = 0
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
         self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
@@ -183,24 +236,44 @@ class FeaturePipeline:
 
                 graphs = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
-        self._graphs = {}  # (slot, shape, dtype, training, engine id) -> dict(calls, graph, static_in, feats, deferred)
+        self._graphs = {}  # (slot, shape, dtype, training, engine id, group) -> dict(calls, graph, static_in, feats, deferred)
+        self._stage = {}   # (slot, shape, dtype) -> stacked input buffer of eager grouped forwards
 
     def __len__(self) -> int:
+        """Batches submitted and not yet handed over."""
         return len(self._queue)
 
+    def free_slots(self) -> int:
+        """Forwards that may still be submitted before ``next()`` has to be called."""
+        return self.depth - len(self._open)
+
+    def resolve_group(self, images: torch.Tensor) -> int:
+        if self.group is None:
+            self.group = default_group(self.model, images, self.depth)
+            if self.group > 1 and self._depth_arg is None and os.environ.get("MVP_INFLIGHT") is None:
+                # grouped forwards: two slots (one group being consumed, the next one's forward running); see default_depth
+                self.depth = 2
+                self.chains = max(1, min(self.depth, self._streams_arg))
+                self.streams = self.streams[:self.chains]
+        return self.group
+
     # ------------------------------------------------------------------ one forward on a slot's stream
-    def _eager(self, slot: int, images: torch.Tensor):
-        with _slot(slot, self.chains):
+    def _eager(self, slot: int, images: torch.Tensor, groups: int = 1):
+        with _slot(slot, self.chains, groups):
             _take_deferred()
             feats = _extract(self.model, images)
             return feats, _take_deferred()
 
-    def _forward(self, slot: int, s, images: torch.Tensor):
-        """Runs on stream ``s`` (current).  Returns (features, deferred updates)."""
-        if not self.graphs:
-            return self._eager(slot, images)
+    def _forward(self, slot: int, s, batches, G: int):
+        """Runs on stream ``s`` (current).  ``batches``: the G image batches of this forward.  Returns (features, deferred updates):
+        for G > 1 a GroupedFeatures and (batch index, update) pairs covering all its batches."""
+        first = batches[0]
+        shape = (G * first.shape[0],) + tuple(first.shape[1:]) if G > 1 else tuple(first.shape)
+        full = G == self.group or G == 1 and self.group in (None, 1)
+        if not (self.graphs and full):
+            return self._eager(slot, self._stacked(slot, batches, shape) if G > 1 else first, G)
         eng = self.model.engine() if hasattr(self.model, "engine") else None
-        key = (slot, tuple(images.shape), images.dtype, bool(self.model.training), id(eng))
+        key = (slot, shape, first.dtype, bool(self.model.training), id(eng), G)
         ent = self._graphs.get(key)
         if ent is None:
             mine = [k for k in self._graphs if k[0] == slot]
@@ -218,65 +291,112 @@ class FeaturePipeline:
                 if other != slot:
                     okey = (other,) + key[1:]
                     oent = self._graphs[okey] = dict(calls=0, graph=None)
-                    self._capture(other, s, images, oent, eng)
+                    self._capture(other, s, batches, shape, G, oent, eng)
         if ent["graph"] is None:
-            return self._capture(slot, s, images, ent, eng)  # (its replay computed this batch's features)
-        ent["static_in"].copy_(images, non_blocking=True)
+            return self._capture(slot, s, batches, shape, G, ent, eng)  # (its replay computed this forward's features)
+        self._fill(ent["static_in"], batches, G)
         ent["graph"].replay()
-        if ent["pack"] is not None:
-            ent["pack"].generation += 1  # the host code that counts rewrites of the packing does not run on a replay
+        for pk in ent["packs"]:
+            pk.generation += 1  # the host code that counts rewrites of the packing does not run on a replay
         return ent["feats"], ent["deferred"]
 
-    def _capture(self, slot: int, s, images: torch.Tensor, ent: dict, eng):
-        """Set a slot up for ``images``' shape: an eager forward (allocates the slot's buffers, builds lazily cached operands — none of
-        that may happen inside a capture), the capture of the very same call, and a first replay on ``images`` (a graph's first launch
+    @staticmethod
+    def _fill(dst: torch.Tensor, batches, G: int) -> None:
+        if G == 1:
+            dst.copy_(batches[0], non_blocking=True)
+            return
+        B = batches[0].shape[0]
+        for g, b in enumerate(batches):
+            dst[g * B:(g + 1) * B].copy_(b, non_blocking=True)
+
+    def _stacked(self, slot: int, batches, shape) -> torch.Tensor:
+        """The [G * B, ...] input of an eager grouped forward: a per-slot staging buffer (reused, so the steady state allocates nothing)."""
+        key = (slot, shape, batches[0].dtype)
+        buf = self._stage.get(key)
+        if buf is None:
+            self._stage = {k: v for k, v in self._stage.items() if k[0] != slot}
+            buf = self._stage[key] = torch.empty(shape, dtype=batches[0].dtype, device=batches[0].device)
+        self._fill(buf, batches, len(batches))
+        return buf
+
+    def _capture(self, slot: int, s, batches, shape, G: int, ent: dict, eng):
+        """Set a slot up for this input shape: an eager forward (allocates the slot's buffers, builds lazily cached operands — none of
+        that may happen inside a capture), the capture of the very same call, and a first replay on the real input (a graph's first launch
         uploads it to the device: that cost belongs here, not in the run).  Returns the replay's (features, deferred updates)."""
         from .vit import lookup_pack
 
-        self._eager(slot, images)
-        static_in = torch.empty_like(images)
+        static_in = torch.empty(shape, dtype=batches[0].dtype, device=batches[0].device)
+        self._fill(static_in, batches, G)
+        self._eager(slot, static_in, G)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):  # other threads (allocator, collectives' watchdog) stay free
-            feats, deferred = self._eager(slot, static_in)
-        ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred,
-                   pack=lookup_pack(feats) if isinstance(feats, (list, tuple)) else None,
+            feats, deferred = self._eager(slot, static_in, G)
+        per_batch = list(feats) if isinstance(feats, GroupedFeatures) else [feats]
+        packs = [pk for pk in (lookup_pack(f) if isinstance(f, (list, tuple)) else None for f in per_batch) if pk is not None]
+        ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred, packs=packs,
                    # the graph holds raw addresses of the slot's buffers and of the engine's operands: both stay alive with it
                    keep=(eng, eng.slot_state(slot) if hasattr(eng, "slot_state") else None))
-        static_in.copy_(images, non_blocking=True)
         g.replay()
         return feats, deferred
 
     def submit(self, images: torch.Tensor) -> None:
-        if len(self._queue) >= self.depth:
+        self.submit_group([images])
+
+    def submit_group(self, batches) -> None:
+        """Enqueue ONE forward over ``batches`` (a list of equal-shaped image batches; a single one = the plain forward)."""
+        batches = list(batches)
+        G = len(batches)
+        if G < 1:
+            raise ValueError("empty group")
+        self.resolve_group(batches[0])
+        if self.free_slots() <= 0:
             raise RuntimeError(f"{self.depth} forwards already in flight: call next() first")
+        if G > 1 and (any(b.shape != batches[0].shape or b.dtype != batches[0].dtype for b in batches) or self.depth == 1):
+            raise ValueError("a grouped forward needs equal-shaped batches and a pipeline of depth >= 2")
         if self.run_ahead > 0 and len(self._issued) >= self.run_ahead:
             self._issued.popleft().synchronize()  # host waits for the forward issued ``run_ahead`` submissions ago
         if self.depth == 1:
-            feats = _extract(self.model, images)
-            if self.run_ahead > 0 and images.is_cuda:
+            feats = _extract(self.model, batches[0])
+            if self.run_ahead > 0 and batches[0].is_cuda:
                 ev = torch.cuda.Event()
                 ev.record()
                 self._issued.append(ev)
             self._queue.append((feats, None, ()))
+            self._open.append(1)
             return
         slot = self._n % self.depth
         s = self.streams[self._n % len(self.streams)]
         self._n += 1
         cur = torch.cuda.current_stream()
-        # the batch is ready on the caller's stream, and the probe step that read this slot's buffers is already enqueued there
+        # the batches are ready on the caller's stream, and the probe steps that read this slot's buffers are already enqueued there
         s.wait_stream(cur)
         with torch.cuda.stream(s):
-            feats, deferred = self._forward(slot, s, images)
+            if self.graphs and self.group > 1 and G != self.group and not self._graphs:
+                # the pipeline's first forward is a ragged group (a warm-up shorter than a group): set the full-group graphs of all
+                # slots up NOW, on copies of this batch, so that no capture falls into the run later (their updates are dropped)
+                self._forward(slot, s, [batches[0]] * self.group, self.group)
+            feats, deferred = self._forward(slot, s, batches, G)
             done = torch.cuda.Event()
             done.record(s)
         if self.run_ahead > 0:
             self._issued.append(done)
-        if images.is_cuda:
-            images.record_stream(s)  # allocated on the caller's stream, read on the side stream
-        self._queue.append((feats, done, deferred))
+        for b in batches:
+            if b.is_cuda:
+                b.record_stream(s)  # allocated on the caller's stream, read on the side stream
+        if G == 1 and not isinstance(feats, GroupedFeatures):
+            self._queue.append((feats, done, [fn for _, fn in deferred]))
+        else:
+            if not isinstance(feats, GroupedFeatures) or len(feats) != G:
+                raise RuntimeError("the backbone did not return one result per batch of the group")
+            for g in range(G):
+                self._queue.append((feats[g], done, [fn for gg, fn in deferred if gg == g]))
+        self._open.append(G)
 
     def next(self):
         feats, done, deferred = self._queue.popleft()
+        self._open[0] -= 1
+        if self._open[0] == 0:
+            self._open.popleft()
         if done is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(done)
@@ -293,6 +413,7 @@ class FeaturePipeline:
             feats, done, deferred = self._queue.popleft()
             if done is not None:
                 torch.cuda.current_stream().wait_event(done)
+        self._open.clear()
 
 
 def _extract(model, images):
@@ -301,17 +422,30 @@ def _extract(model, images):
     return extract_features(model, images)
 
 
-def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None, probe=None) -> Iterator[Tuple[object, object]]:
-    """Yield ``(batch, features)`` for every batch of ``batches`` with up to ``depth`` forwards in flight: the forward of batch
-    t+1 is enqueued before batch t is handed to the caller, so it runs under the caller's probe step t.  ``depth`` None:
-    ``default_depth(probe)``."""
-    pipe = FeaturePipeline(model, default_depth(probe) if depth is None else depth)
+def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None, probe=None, group: int = None,
+                       pipe: "FeaturePipeline" = None) -> Iterator[Tuple[object, object]]:
+    """Yield ``(batch, features)`` for every batch of ``batches`` with up to ``depth`` forwards in flight: the forwards of the next
+    batches are enqueued before batch t is handed to the caller, so they run under the caller's probe step t.  ``depth`` None:
+    ``default_depth(probe)``.  Consecutive equal-shaped batches are stacked ``group`` at a time into one forward (None:
+    ``default_group``; an epoch's ragged last batch and whatever is left over run as smaller forwards).  ``pipe``: an existing
+    pipeline to reuse (its captured graphs); it must be empty."""
+    if pipe is None:
+        if depth is None:
+            d = default_depth(probe)
+            # 1 (DPT probe, ranks rehearsing on one card, MVP_INFLIGHT=1) is final; otherwise the pipeline picks its own default once it
+            # knows whether the forwards are grouped (2 slots) or single batches (4)
+            depth = d if (d == 1 or os.environ.get("MVP_INFLIGHT") is not None) else None
+        pipe = FeaturePipeline(model, depth, group=group)
+    elif len(pipe):
+        raise RuntimeError("pipelined_features needs an empty pipeline")
     if hasattr(batches, "consumer_lag"):
-        # mvp.prefetch.DevicePrefetcher recycles its device buffers: this generator holds pipe.depth batches before the caller has
-        # issued the probe step of the first of them (which reads that batch's target; its image is read by the forward in flight)
-        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth - 1)
+        # mvp.prefetch.DevicePrefetcher recycles its device buffers (it sizes its pool when its first batch is pulled): this generator
+        # holds up to depth x group batches before the caller has issued the probe step of the first of them (which reads that batch's
+        # target; its image is read by the forward in flight).  The group size is not known before the first batch: its upper bound.
+        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth * (pipe.group or MAX_GROUP) - 1)
     it = iter(batches)
     pending = collections.deque()
+    held = []  # a batch pulled from the iterator that did not fit the group being formed
 
     def images_of(b):
         x = b[image_key] if isinstance(b, dict) else b[0]
@@ -319,18 +453,36 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
             return x
         return x.to(torch.device("cuda", torch.cuda.current_device()), non_blocking=True)
 
-    def feed() -> bool:
+    def pull():
+        if held:
+            return held.pop()
         try:
             b = next(it)
         except StopIteration:
+            return None
+        return b, images_of(b)
+
+    def feed() -> bool:
+        first = pull()
+        if first is None:
             return False
-        pipe.submit(images_of(b))
-        pending.append(b)
+        G = pipe.resolve_group(first[1])
+        grp = [first]
+        while len(grp) < G:
+            nxt = pull()
+            if nxt is None:
+                break
+            if nxt[1].shape != first[1].shape or nxt[1].dtype != first[1].dtype:
+                held.append(nxt)
+                break
+            grp.append(nxt)
+        pipe.submit_group([x for _, x in grp])
+        pending.extend(b for b, _ in grp)
         return True
 
     try:
         while True:
-            while len(pipe) < pipe.depth and feed():
+            while pipe.free_slots() > 0 and feed():
                 pass
             if not pending:
                 break

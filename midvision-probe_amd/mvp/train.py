@@ -14,12 +14,17 @@ from .pipeline import freeze_gc, pipelined_features
 def extract_features(model, images, detach_model=True):
     """train_depth.py:103-112."""
     if detach_model:
+        from .pipeline import GroupedFeatures
+
+        def _detached(f):
+            return [_f.detach() for _f in f] if isinstance(f, (tuple, list)) else f.detach()
+
         with torch.no_grad():
             feats = model(images)
-            if isinstance(feats, (tuple, list)):
-                feats = [_f.detach() for _f in feats]
+            if isinstance(feats, GroupedFeatures):  # several batches stacked into one forward (mvp/pipeline.py): one result per batch
+                feats = GroupedFeatures(_detached(f) for f in feats)
             else:
-                feats = feats.detach()
+                feats = _detached(feats)
     else:
         # every head Function returns None for the feature gradient and the backbone engines run under no_grad: a
         # trainable backbone (optimizer.model_lr != 0, train_depth.py:566-575) would silently train nothing

@@ -41,6 +41,10 @@ class TapOutputs(list):
     packed = None
 
 
+class TapGroups(list):
+    """What a GROUPED forward returns (``forward_taps(..., groups=G)``): one ``TapOutputs`` per batch of the group, in batch order."""
+
+
 class PackedFeatures:
     """Token-major operand of the linear-probe GEMMs: F [Mpad, Cpad] bf16 pair (forward: F·Wᵀ by the NT GEMM;
     weight gradient: gᵀ·F by the TN split-K kernel, which reads the same row-major image through transposed LDS reads)."""
@@ -58,7 +62,7 @@ class PackedFeatures:
 
 
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
-_PACK_REGISTRY_MAX = 16
+_PACK_REGISTRY_MAX = 64  # one entry per (pipeline slot, batch of a grouped forward)
 
 
 def _ver(t: torch.Tensor) -> int:
@@ -127,6 +131,9 @@ class ViTEngine:
                 fc1_w=ops.split_bf16(sd[p + "mlp.fc1.weight"], self.precision), fc1_b=sd[p + "mlp.fc1.bias"],
                 fc2_w=ops.split_bf16(sd[p + "mlp.fc2.weight"], self.precision), fc2_b=sd[p + "mlp.fc2.bias"],
             )
+            if self.precision == PREC_BF16X3:  # hi|lo-interleaved copies of the frozen weights for the large-M GEMM kernel (mvp.ops.interleave_pair)
+                for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w"):
+                    blk[n + "_ilv"] = ops.interleave_pair(blk[n])
             self.blocks.append(blk)
         self.hidden = self.blocks[0]["fc1_b"].numel()
         self._ws: Dict[Tuple[int, int, int, int], dict] = {}  # (B, gh, gw, pipeline slot)
@@ -160,8 +167,8 @@ class ViTEngine:
         """Every buffer set this engine currently keeps for pipeline slot ``slot`` (activation workspaces, feature packings, output
         maps).  A captured hipGraph of that slot's forward holds their raw addresses: the pipeline keeps this list alive with the
         graph, because the engine itself drops the buffers of other resolutions when a new one arrives."""
-        return ([v for k, v in self._ws.items() if k[-1] == slot] + [v for k, v in self._packs.items() if k[-1] == slot]
-                + [v for k, v in self._slot_outs.items() if k[-1] == slot] + list(self._pos.values()))
+        return ([v for k, v in self._ws.items() if k[-1] == slot] + [v for k, v in self._packs.items() if k[-2] == slot]
+                + [v for k, v in self._slot_outs.items() if k[-2] == slot] + list(self._pos.values()))
 
     def pos_for(self, gh: int, gw: int, dim2: int, dim3: int) -> torch.Tensor:
         """Pos-embed for a gh x gw grid.  'dino': bicubic resize with the +0.1 scale nudge of
@@ -216,91 +223,107 @@ class ViTEngine:
         blk, C, M, pr = self.blocks[i], self.C, B * N, self.precision
         x = ws["x"]
         ops.layernorm(x, blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps)
-        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=pr)
+        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=pr, w_ilv=blk.get("qkv_w_ilv"))
         ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr)
-        ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=pr)
+        ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=pr, w_ilv=blk.get("proj_w_ilv"))
         ops.layernorm(x, blk["n2w"], blk["n2b"], ws["xn"], M, C, self.ln_eps)
-        ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=pr)
-        ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=pr)
+        ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=pr, w_ilv=blk.get("fc1_w_ilv"))
+        ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=pr, w_ilv=blk.get("fc2_w_ilv"))
 
     def forward_taps(self, images: torch.Tensor, layers: Sequence[int], *, bn: Optional[Sequence[dict]] = None,
-                     bn_mode: int = 0, pack: bool = True, tap_input_of_block: bool = False, want_cls: bool = False) -> TapOutputs:
+                     bn_mode: int = 0, pack: bool = True, tap_input_of_block: bool = False, want_cls: bool = False, groups: int = 1):
         """Run blocks up to the last tapped one; at each tap apply the (train-mode) tap BN and
         emit the NCHW map (+ token-major packing).  ``bn[j]`` = dict(weight,bias,running_mean,
         running_var) tensors or None; bn_mode: 0 train stats, 1 eval, 2 no norm.
         ``tap_input_of_block``: tap the INPUT of block i instead of its output (HF
-        hidden_states indexing used by the MAE wrapper, quirk Q4)."""
-        ws, B, gh, gw = self.tokens(images)
+        hidden_states indexing used by the MAE wrapper, quirk Q4).
+        ``groups`` = G > 1: ``images`` holds G batches of equal size stacked along dim 0 (mvp/pipeline.py).  Patch embedding,
+        LayerNorm, the GEMMs and attention are per-row / per-image, so the G batches simply share their launches (M = G * B * N
+        rows: the large-M GEMM kernel); the tap BN — train-mode statistics over ONE batch (dino.py:185-191) — runs per batch on that
+        batch's rows.  Every batch gets exactly the bits it would get alone; returns ``TapGroups`` (one ``TapOutputs`` per batch)."""
+        ws, Bt, gh, gw = self.tokens(images)
+        if groups < 1 or Bt % groups:
+            raise lib.MvpError(f"grouped forward: {Bt} images do not split into {groups} equal batches")
+        G, B = groups, Bt // groups
         N, C, hw = 1 + gh * gw, self.C, gh * gw
         layers = list(layers)
-        outs = TapOutputs()
-        packed = None
+        outs_g = [TapOutputs() for _ in range(G)]
+        packed_g = [None] * G
         if pack:  # reuse the (zero padded) packing buffers across steps: only the valid region is rewritten
-            pkey = (B, gh, gw, len(layers), pipeline.current_slot())
-            packed = self._packs.get(pkey)
-            if packed is None:
-                packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device)
-                self._packs = {k: v for k, v in self._packs.items() if k[:4] == pkey[:4]}
-                self._packs[pkey] = packed
-            packed.generation += 1
+            for g in range(G):
+                pkey = (B, gh, gw, len(layers), pipeline.current_slot(), g)
+                packed = self._packs.get(pkey)
+                if packed is None:
+                    packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device)
+                    self._packs = {k: v for k, v in self._packs.items() if k[:4] == pkey[:4]}
+                    self._packs[pkey] = packed
+                packed.generation += 1
+                packed_g[g] = packed
         # Plain calls return freshly allocated maps (the caller may keep them).  A pipelined forward (mvp/pipeline.py) writes into
         # buffers owned by its slot instead — valid until the slot's next forward, which is the pipeline's contract — so the
         # steady state allocates nothing and no block ever changes hands between the side stream's and the trainer's allocator pools.
-        slot_out = None
+        slot_out_g = [None] * G
         if pipeline.pipelined():
-            okey = (B, gh, gw, tuple(layers), bool(want_cls), pipeline.current_slot())
-            slot_out = self._slot_outs.get(okey)
-            if slot_out is None:
-                slot_out = dict(stats=torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device),
-                                nchw=[torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device) for _ in layers],
-                                cls=[torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None for _ in layers])
-                self._slot_outs = {k: v for k, v in self._slot_outs.items() if k[:5] == okey[:5]}
-                self._slot_outs[okey] = slot_out
-        stats = slot_out["stats"] if slot_out else torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device)
-
-        outs.cls = []
+            for g in range(G):
+                okey = (B, gh, gw, tuple(layers), bool(want_cls), pipeline.current_slot(), g)
+                slot_out = self._slot_outs.get(okey)
+                if slot_out is None:
+                    slot_out = dict(stats=torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device),
+                                    nchw=[torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device) for _ in layers],
+                                    cls=[torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None for _ in layers])
+                    self._slot_outs = {k: v for k, v in self._slot_outs.items() if k[:5] == okey[:5]}
+                    self._slot_outs[okey] = slot_out
+                slot_out_g[g] = slot_out
+        stats_g = [so["stats"] if so else torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device) for so in slot_out_g]
+        for o in outs_g:
+            o.cls = []
 
         # Train-mode tap BN updates its running statistics in place: the only state a frozen forward mutates.  Forwards in flight on
         # different streams finish in any order, so a pipelined forward leaves that update to the consumer (pipeline.defer), which
         # applies it on the trainer's stream in batch order — same arithmetic, same bits (mvp_bn_running_update).
         defer = bn is not None and bn_mode == 0 and pipeline.pipelined()
+        if G > 1 and bn is not None and bn_mode == 0 and not defer:
+            raise lib.MvpError("a grouped forward with train-mode tap BN must run under the pipeline (its running-statistics updates are per batch)")
 
         def tap(j):
-            if slot_out:
-                nchw, cls = slot_out["nchw"][j], slot_out["cls"][j]
-            else:
-                nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
-                cls = torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None
-            if want_cls:
-                outs.cls.append(cls)
-            b = bn[j] if bn is not None else None
-            ops.bn_tokens_to_nchw(
-                ws["x"], B, N, C, hw, workspace=ws["bn_ws"], stats=stats[j],
-                gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
-                running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
-                nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
-                mode=bn_mode, cls_out=cls, num_batches_tracked=b.get("num_batches_tracked") if b else None, defer_running=defer)
-            if defer and b is not None and b.get("running_mean") is not None:
-                st = stats[j]
-                pipeline.defer(lambda st=st, b=b: ops.bn_running_update(st, b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C))
-            outs.append(nchw)
+            for g in range(G):
+                slot_out, packed, outs = slot_out_g[g], packed_g[g], outs_g[g]
+                if slot_out:
+                    nchw, cls = slot_out["nchw"][j], slot_out["cls"][j]
+                else:
+                    nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
+                    cls = torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None
+                if want_cls:
+                    outs.cls.append(cls)
+                b = bn[j] if bn is not None else None
+                xg = ws["x"] if G == 1 else ws["x"][g * B * N:(g + 1) * B * N]  # this batch's rows of the residual stream
+                ops.bn_tokens_to_nchw(
+                    xg, B, N, C, hw, workspace=ws["bn_ws"], stats=stats_g[g][j],
+                    gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
+                    running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
+                    nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
+                    mode=bn_mode, cls_out=cls, num_batches_tracked=b.get("num_batches_tracked") if b else None, defer_running=defer)
+                if defer and b is not None and b.get("running_mean") is not None:
+                    st = stats_g[g][j]
+                    pipeline.defer(lambda st=st, b=b: ops.bn_running_update(st, b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C), group=g)
+                outs.append(nchw)
 
-        last = max(layers)
         for i in range(self.depth):
             if tap_input_of_block and i in layers:
                 tap(layers.index(i))
-                if len(outs) == len(layers):
+                if len(outs_g[0]) == len(layers):
                     break
-            self.run_block(i, ws, B, N)
+            self.run_block(i, ws, Bt, N)
             if (not tap_input_of_block) and i in layers:
                 tap(layers.index(i))
-                if len(outs) == len(layers):
+                if len(outs_g[0]) == len(layers):
                     break
-        outs.stats = stats
-        if packed is not None:
-            outs.packed = packed
-            register_pack(outs, packed)
-        return outs
+        for g in range(G):
+            outs_g[g].stats = stats_g[g]
+            if packed_g[g] is not None:
+                outs_g[g].packed = packed_g[g]
+                register_pack(outs_g[g], packed_g[g])
+        return outs_g[0] if G == 1 else TapGroups(outs_g)
 
     def forward_tokens(self, images: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
         """Raw fp32 token stream after ``n_blocks`` blocks ([B, N, C]); for tests / CLS outputs."""

@@ -321,21 +321,22 @@ def test_prefetcher_buffers_survive_the_pipelines_look_ahead():
         g = torch.Generator().manual_seed(700 + s)
         host.append({"image": torch.randn(4, 3, 64, 80, generator=g).pin_memory(), "depth": (torch.rand(4, 1, 64, 80, generator=g) * 9 + 0.05).pin_memory()})
 
-    def run(depth):
+    def run(depth, group):
         model, probe, opt, sched = _build(dev)
         loss_fn = DepthLoss()
         pre = DevicePrefetcher(host, dev, depth=2)
         losses = []
-        for batch, feats in pipelined_features(model, pre, depth=depth):
+        for batch, feats in pipelined_features(model, pre, depth=depth, group=group):
             losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, batch["depth"], feats=feats))
         torch.cuda.synchronize()
-        assert pre.consumer_lag == depth - 1
+        assert pre.consumer_lag == depth * group - 1
         return torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy()
 
-    ref = run(1)
-    got = run(4)
-    np.testing.assert_array_equal(got[0], ref[0])
-    np.testing.assert_array_equal(got[1], ref[1])
+    ref = run(1, 1)
+    for depth, group in ((4, 1), (2, 3)):  # 4 single-batch forwards ahead; 2 forwards of 3 stacked batches ahead (6 batches held)
+        got = run(depth, group)
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
 
 
 def test_leaving_the_loop_early_discards_the_forwards_in_flight():
@@ -361,3 +362,123 @@ def test_leaving_the_loop_early_discards_the_forwards_in_flight():
     assert ref[0] == got[0] == [3] * 4
     np.testing.assert_array_equal(got[1], ref[1])
     np.testing.assert_array_equal(got[2], ref[2])
+
+
+# ---------------------------------------------------------------------------------------------------------------- grouped forwards
+def _run_grouped(group, depth, n=7, graphs=False, B=4, hw=(64, 80), streams=None):
+    """The same trajectory as ``_run`` with ``group`` batches stacked into every frozen forward (mvp/pipeline.py, module docstring)."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    model, probe, opt, sched = _build(dev)
+    loss_fn = DepthLoss()
+    bs = _batches(dev, n, B=B, hw=hw)
+    pipe = FeaturePipeline(model, depth, graphs=graphs, group=group, streams=streams)
+    losses = [train_depth_step(model, probe, opt, sched, loss_fn, None, b["depth"].clone(), feats=f) for b, f in pipelined_features(model, bs, pipe=pipe)]
+    torch.cuda.synchronize()
+    bn = [torch.cat([b.running_mean, b.running_var]).cpu().numpy() for b in model.batchnorms]
+    nbt = [int(b.num_batches_tracked) for b in model.batchnorms]
+    return (torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(), opt.exp_avg_sq.cpu().numpy().copy(), bn, nbt), pipe
+
+
+@pytest.mark.parametrize("group,depth,graphs", [(3, 2, False), (2, 2, True), (3, 2, True), (4, 3, True)])
+def test_grouped_forwards_are_bit_identical_to_serial(group, depth, graphs):
+    """7 batches through groups of 3 + 3 + 1 (2 + 2 + 2 + 1, 4 + 3): the batches of a group share every launch of the frozen forward
+    except the tap BN (train-mode statistics of ONE batch, dino.py:185-191), whose running-statistics updates are applied per batch
+    in batch order.  Losses, probe weights, AdamW state, running statistics and step counters equal the one-batch-at-a-time loop's
+    (train_depth.py:99-143) bit for bit; with graphs, full groups replay a captured hipGraph and the ragged last group runs eagerly."""
+    ref = _run(1)
+    got, pipe = _run_grouped(group, depth, graphs=graphs)
+    assert pipe.group == group and pipe.depth == depth
+    if graphs:
+        assert len(pipe._graphs) == depth and all(e["graph"] is not None and k[-1] == group for k, e in pipe._graphs.items())
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    for a, b in zip(got[3], ref[3]):
+        np.testing.assert_array_equal(a, b)
+    assert got[4] == ref[4] == [7] * 4
+
+
+def test_warmup_shorter_than_a_group_sets_the_full_group_graphs_up():
+    """bench.py's shape: a warm-up of fewer batches than one group, then full groups.  The full-group graphs of every slot are captured
+    at the pipeline's FIRST submit (on copies of that batch, updates dropped), so the later full groups only replay."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    ref = _run(1, n=8)
+    model, probe, opt, sched = _build(dev)
+    loss_fn = DepthLoss()
+    bs = _batches(dev, 8)
+    pipe = FeaturePipeline(model, 2, graphs=True, group=3)
+    losses = []
+    for leg, part in enumerate((bs[:2], bs[2:])):  # warm-up of 2 (one ragged group), then 3 + 3
+        for b, f in pipelined_features(model, part, pipe=pipe):
+            losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, b["depth"].clone(), feats=f))
+        if leg == 0:
+            assert len(pipe._graphs) == 2 and all(e["graph"] is not None for e in pipe._graphs.values())
+            calls = sum(e["calls"] for e in pipe._graphs.values())
+    assert sum(e["calls"] for e in pipe._graphs.values()) == calls + 2  # the two full groups replayed; nothing new was captured
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(torch.stack(losses).cpu().numpy(), ref[0])
+    np.testing.assert_array_equal(opt.flat_param.cpu().numpy(), ref[1])
+    assert [int(b.num_batches_tracked) for b in model.batchnorms] == [8] * 4
+
+
+def test_timed_configuration_b16_224_grouped_graphs_vs_serial_and_oracle():
+    """What bench.py times by default (VERDICT r2 #2b): B = 16, 224^2, six batches per frozen forward (M = 18912 token rows: the
+    large-M ping-pong GEMM kernel, csrc/gemm_pp.hip), hipGraph replay, 2 forwards in flight.  (a) the trajectory over 8 batches
+    (groups 6 + 2) equals the serial one-batch-at-a-time loop bit for bit; (b) the tap features of a batch INSIDE a group equal the
+    CPU oracle's (reference restatement, oracle/vit.py) to <= 1e-3 rel-L2, and its loss the oracle trainer's."""
+    from evals.models.dino import DINO
+    from evals.models.probes import DepthHead
+    from evals.utils.losses import DepthLoss
+    from mvp.optim import FlatAdamW
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+    from mvp.train import train_depth_step
+    from oracle import probes as oprobes
+    from oracle import train as otrain
+    from oracle import vit as ovit
+
+    dev = torch.device("cuda:0")
+    vsd = ovit.make_vit_weights(seed=0)
+    psd = oprobes.make_linear_head_weights([768] * 4, 256, 1, seed=3)
+    B, n = 16, 8
+    host = [otrain.synthetic_depth_batch(B, 224, 224, rank=0, step=s) for s in range(n)]
+    bs = [(i.to(dev), t.to(dev)) for i, t in host]
+
+    def run(depth, group, graphs):
+        model = DINO(return_multilayer=True, add_norm=True, weights=vsd).to(dev)
+        probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth")
+        probe.load_state_dict(psd, strict=True)
+        probe = probe.to(dev)
+        opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}])
+        pipe = FeaturePipeline(model, depth, graphs=graphs, group=group)
+        losses, kept = [], None
+        for i, ((img, tgt), f) in enumerate(pipelined_features(model, bs, pipe=pipe)):
+            if i == 4:
+                kept = [t.clone() for t in f]  # features of the fifth batch: inside the first group of six
+            losses.append(train_depth_step(model, probe, opt, None, DepthLoss(), None, tgt.clone(), feats=f))
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(), [k.cpu().numpy() for k in kept], [b.running_var.cpu().numpy() for b in model.batchnorms]
+
+    ref = run(1, 1, False)
+    got = run(2, 6, True)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(got[3], ref[3]):
+        np.testing.assert_array_equal(a, b)
+    # (b) against the CPU oracle: batch 4 alone (its tap BN statistics are its own), first-step loss of the trajectory
+    tr = otrain.DepthProbeTrainer(vsd, psd, max_step=100, warmup_step=10)
+    feats_ref = tr.features(host[4][0])
+    for f, fr in zip(got[2], feats_ref):
+        d = f.astype(np.float64) - fr.numpy().astype(np.float64)
+        assert np.sqrt((d * d).sum() / (fr.numpy().astype(np.float64) ** 2).sum()) < 1e-3
+    loss0, _ = tr.forward_loss(tr.features(host[0][0]), host[0][1].clone())
+    assert abs(got[0][0] - loss0.item()) < 2e-3 * abs(loss0.item())

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Ping-pong 256x256 bf16x3 GEMM (csrc/gemm_pp.hip): correctness against fp64 and against the tile kernels (bit-identity),
+then timing, interleaved rounds in one process, on random operands.
+
+  python tools/pp_bench.py [--check-only] [--B 64] [--ablate]
+
+Variants timed: `tile` = mvp_gemm_bias_act_res (ALONE rule), `shared` = the same with MVP_TILES_SHARED, `pp_sep` = the new kernel on
+separate hi / lo arrays, `pp_ilv` = the new kernel on hi|lo-interleaved operands (re-laid out here with torch)."""
+import ctypes as C, os, subprocess, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "midvision-probe_amd"))
+import torch
+from mvp import lib, ops
+
+CS = os.path.join(REPO, "midvision-probe_amd", "csrc")
+OUT = os.path.join(REPO, "gpurun_out")
+
+
+def interleave(pair):
+    """(hi, lo) [R, K] -> one [R, 2K] array, hi | lo interleaved per 32-deep k block."""
+    hi, lo = pair
+    R, K = hi.shape
+    return torch.stack((hi.view(R, K // 32, 32), lo.view(R, K // 32, 32)), dim=2).reshape(R, 2 * K).contiguous()
+
+
+def build_ablate(n, define="MVP_PP_ABLATE", tag="ab"):
+    """Ablated copies of gemm_pp.hip, built with the product's flags (csrc/Makefile print-cxxflags) into tools/micro/ — build them in
+    the build container (they travel to the GPU box with the tree); an existing one is reused."""
+    so = os.path.join(REPO, "tools", "micro", f"libpp_{tag}{n}.so")
+    if not os.path.exists(so):
+        fl = subprocess.run(["make", "-s", "-C", CS, "print-cxxflags"], capture_output=True, text=True, check=True).stdout.strip()
+        fl = fl.replace("-I../../include", f"-I{REPO}/include")
+        cmd = f"set -o pipefail; /opt/rocm/bin/hipcc {fl} -shared -I{CS} -D{define}={n} -w {CS}/gemm_pp.hip -o {so} 2>&1 | {{ grep -v 'recognized feature' || true; }}"
+        subprocess.run(["bash", "-c", cmd], check=True)
+    l = C.CDLL(so)
+    l.mvp_gemm_pp.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
+    l.mvp_gemm_pp.restype = C.c_int
+    return l
+
+
+def main():
+    dev = torch.device("cuda")
+    L = lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(0)
+    ok = True
+
+    def mk(m, n, k, *, bias=True, act=0, residual=False, pair_out=True, f32_out=False):
+        a = ops.split_bf16(torch.randn(m, k, device=dev), 3)
+        w = ops.split_bf16(torch.randn(n, k, device=dev) * 0.05, 3)
+        b = torch.randn(n, device=dev) if bias else None
+        r = torch.randn(m, n, device=dev) if residual else None
+        return dict(a=a, w=w, ai=interleave(a), wi=interleave(w), bias=b, res=r, act=act, m=m, n=n, k=k, pair_out=pair_out, f32_out=f32_out)
+
+    def args_for(d, layout, out, o32):
+        """layout: mvp_gemm_args.pair_layout — bit 0: A interleaved, bit 1: W interleaved."""
+        layout = int(layout)
+        ia, iw = bool(layout & 1), bool(layout & 2)
+        k = d["k"]
+        g = lib.GemmArgs(d["ai"].data_ptr() if ia else d["a"][0].data_ptr(), None if ia else d["a"][1].data_ptr(),
+                         d["wi"].data_ptr() if iw else d["w"][0].data_ptr(), None if iw else d["w"][1].data_ptr(),
+                         lib.ptr(d["bias"]), lib.ptr(d["res"]), lib.ptr(o32), lib.ptr(out[0]) if out else None, lib.ptr(out[1]) if out else None,
+                         d["m"], d["n"], k, 2 * k if ia else k, 2 * k if iw else k, d["n"], d["n"], d["n"], d["act"], 3, 0, 0, 0, 0)
+        g.pair_layout = layout
+        return g
+
+    def run(d, which, out, o32, libpp=None):
+        if which in ("tile", "shared"):
+            g = args_for(d, False, out, o32)
+            g.tile_policy = (1 if which == "shared" else 0) | 2  # MVP_TILES_NO_PP: the tile kernels themselves
+            rc = L.mvp_gemm_bias_act_res(C.byref(g), st)
+        else:
+            layout = {"sep": 0, "ailv": 1, "wilv": 2, "ilv": 3}[which.rsplit("_", 1)[1]]
+            g = args_for(d, layout, out, o32)
+            rc = (libpp or L).mvp_gemm_pp(C.byref(g), st)
+        if rc != 0:
+            raise RuntimeError(f"{which}: rc {rc}")
+
+    # ------------------------------------------------------------------ correctness
+    cases = [(256, 256, 64, {}), (300, 520, 96, dict(act=1)), (3152, 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
+             (3152, 2304, 768, {}), (1000, 3072, 768, dict(act=1)), (777, 768, 3072, dict(residual=True, f32_out=True)),
+             (12608, 768, 768, dict(residual=True, pair_out=False, f32_out=True))]
+    for m, n, k, kw in cases:
+        d = mk(m, n, k, **kw)
+        A = (d["a"][0].double() + d["a"][1].double())
+        W = (d["w"][0].double() + d["w"][1].double())
+        ref = A @ W.t() + d["bias"].double()
+        if d["act"] == 1:
+            ref = torch.nn.functional.gelu(ref)
+        if d["res"] is not None:
+            ref = ref + d["res"].double()
+        outs = {}
+        for which in ("tile", "pp_sep", "pp_ilv", "pp_wilv", "pp_ailv"):
+            out = ops.empty_pair((m, n), 3, dev) if d["pair_out"] else None
+            o32 = torch.empty(m, n, device=dev) if d["f32_out"] else None
+            if out:
+                out[0].fill_(float("nan")); out[1].fill_(float("nan"))
+            if o32 is not None:
+                o32.fill_(float("nan"))
+            run(d, which, out, o32)
+            torch.cuda.synchronize()
+            val = o32.double() if o32 is not None else (out[0].double() + out[1].double())
+            err = ((val - ref).abs().max() / ref.abs().max()).item()
+            outs[which] = (out, o32, err)
+        same = {}
+        for which in ("pp_sep", "pp_ilv", "pp_wilv", "pp_ailv"):
+            o, o32, _ = outs[which]
+            t, t32, _ = outs["tile"]
+            eq = True
+            if o32 is not None:
+                eq = eq and torch.equal(o32, t32)
+            if o is not None:
+                eq = eq and torch.equal(o[0], t[0]) and torch.equal(o[1], t[1])
+            same[which] = eq
+        good = all(v[2] < 2e-5 for v in outs.values()) and all(same.values())
+        ok = ok and good
+        print(f"check M={m} N={n} K={k} {kw}: rel-max-err tile {outs['tile'][2]:.2e} pp_sep {outs['pp_sep'][2]:.2e} pp_ilv {outs['pp_ilv'][2]:.2e}; "
+              f"bit-identical to tile: {same}  {'OK' if good else 'FAIL'}", flush=True)
+    # reproducibility / race screen: the same launch many times must give the same bits
+    d = mk(3152, 768, 3072, residual=True, pair_out=False, f32_out=True)
+    for which in ("pp_sep", "pp_ilv"):
+        base = torch.empty(3152, 768, device=dev)
+        run(d, which, None, base)
+        bad = 0
+        for _ in range(200):
+            o = torch.empty(3152, 768, device=dev)
+            run(d, which, None, o)
+            bad += int(not torch.equal(o, base))
+        ok = ok and bad == 0
+        print(f"repro {which}: {bad} of 200 launches differ", flush=True)
+    print("CHECK", "PASS" if ok else "FAIL", flush=True)
+    if "--build-only" in sys.argv:
+        return 0
+    if "--check-only" in sys.argv or not ok:
+        return 0 if ok else 1
+
+    if "--stamp" in sys.argv:  # in-kernel s_memtime breakdown of the phases (diagnostic build, MVP_PP_STAMP)
+        lst = build_ablate(1, "MVP_PP_STAMP", "stamp")
+        names = ["issue (reads + DMA)", "counted waits", "barrier 1", "MFMA cluster", "barrier 2"]
+        for B in (64, 96):
+            M = B * 197
+            for name, n, k, kw in (("qkv", 2304, 768, {}), ("fc2", 768, 3072, dict(residual=True, pair_out=False, f32_out=True))):
+                for ilv in (1, 0):
+                    d = mk(M, n, k, **kw)
+                    out = ops.empty_pair((M, n), 3, dev) if d["pair_out"] else None
+                    o32 = torch.empty(M, n, device=dev) if d["f32_out"] else None
+                    tiles = ((M + 255) // 256) * ((n + 255) // 256)
+                    dbg = torch.zeros(tiles * 2 * 10, dtype=torch.int64, device=dev)
+                    g = args_for(d, 3 if ilv else 0, out, o32)
+                    g.splitk_ws, g.splitk_ws_bytes = dbg.data_ptr(), dbg.numel() * 8
+                    for _ in range(3):
+                        rc = lst.mvp_gemm_pp(C.byref(g), st)
+                    torch.cuda.synchronize()
+                    assert rc == 0
+                    t = dbg.view(tiles, 2, 2, 5).double() / (k // 32)  # cycles per phase, [tile, group, phase type, segment]
+                    mean = t.mean(dim=0)
+                    print(f"stamp B={B} {name} ilv={ilv} tiles={tiles}: cycles per phase (mean over workgroups; group 0 | group 1)")
+                    for ph in range(2):
+                        print(f"   P{ph + 1}: " + "  ".join(f"{names[c]}={mean[0, ph, c]:.0f}|{mean[1, ph, c]:.0f}" for c in range(5))
+                              + f"   total={mean[0, ph].sum():.0f}|{mean[1, ph].sum():.0f}", flush=True)
+        return 0
+
+    # ------------------------------------------------------------------ timing
+    Bs = [int(x) for x in (sys.argv[sys.argv.index("--B") + 1].split(",") if "--B" in sys.argv else ["16", "64", "96"])]
+    variants = ["tile", "pp_sep", "pp_wilv", "pp_ailv", "pp_ilv"]
+    extra = {}
+    if "--ablate" in sys.argv:
+        for n, nm in ((1, "no_mfma"), (2, "no_dma"), (3, "no_read")):
+            extra[nm] = build_ablate(n)
+    for B in Bs:
+        M = B * 197
+        for name, n, k, kw in (("qkv", 2304, 768, {}), ("proj", 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
+                               ("fc1", 3072, 768, dict(act=1)), ("fc2", 768, 3072, dict(residual=True, pair_out=False, f32_out=True))):
+            d = mk(M, n, k, **kw)
+            out = ops.empty_pair((M, n), 3, dev) if d["pair_out"] else None
+            o32 = torch.empty(M, n, device=dev) if d["f32_out"] else None
+            res = {}
+            todo = [(v, None) for v in variants] + [(nm + "_ilv", l) for nm, l in extra.items()]
+            for rnd in range(3):
+                for vn, lpp in todo:
+                    for _ in range(2):
+                        run(d, vn, out, o32, lpp)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        run(d, vn, out, o32, lpp)
+                    e1.record(); torch.cuda.synchronize()
+                    res.setdefault(vn, []).append(e0.elapsed_time(e1) / 10 * 1e3)
+            fl = 2.0 * M * n * k
+            print(f"B={B:3d} {name:5s} M={M} N={n} K={k}: " + "  ".join(f"{vn}={min(v):7.1f}us({fl / min(v) / 1e6:4.0f}TF)" for vn, v in res.items()), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
