@@ -150,6 +150,10 @@ typedef struct {
    *   (ldw) is its row stride in elements (2 * K when dense), a_lo (w_lo) is ignored.  Only the large-M kernel (mvp_gemm_pp) reads
    *   this layout; MVP_PAIR_ILV32 (3) = both operands.                                                                           */
   int pair_layout;
+  /* --- layout of the bf16-pair OUTPUT (out_hi / out_lo): MVP_PAIR_SEPARATE, or MVP_PAIR_A_ILV32 (1): out_hi is ONE array
+   * [rows][N / 32][hi 32 | lo 32] with row stride ldob (2 * N when dense), out_lo is ignored, N % 32 == 0 — the A operand of a following
+   * large-M GEMM (fc1 -> fc2).  Any kernel of mvp_gemm_bias_act_res writes it.                                                        */
+  int out_pair_layout;
 } mvp_gemm_args;
 #define MVP_TILES_ALONE 0
 #define MVP_TILES_SHARED 1
@@ -181,6 +185,8 @@ typedef struct {
   float* out_f32;                     /* optional fp32 copy, or NULL */
   int M, C;                           /* C % 8 == 0, C <= 2048 */
   float eps;
+  int out_layout;                     /* MVP_PAIR_SEPARATE, or MVP_PAIR_A_ILV32 (1): out_hi is ONE [M][C / 32][hi 32 | lo 32] array (row stride
+                                         2 * C), out_lo ignored, C % 32 == 0 — the A operand of the large-M GEMM (mvp_gemm_args.pair_layout) */
 } mvp_layernorm_args;
 int mvp_layernorm_fwd(const mvp_layernorm_args*, void* stream);
 
@@ -198,6 +204,8 @@ typedef struct {
   int ld_qkv, ld_out;
   float scale;      /* head_dim^-0.5 */
   int precision;
+  int out_layout;   /* MVP_PAIR_SEPARATE, or MVP_PAIR_A_ILV32 (1): out_hi is ONE [B*N][H*2][hi 32 | lo 32] array with row stride ld_out
+                       (>= 2 * H * 64), out_lo ignored — the A operand of the large-M proj GEMM (mvp_gemm_args.pair_layout)               */
 } mvp_attention_args;
 int mvp_attention_fwd(const mvp_attention_args*, void* stream);
 
@@ -244,6 +252,14 @@ typedef struct {
                            variance to stats[2*C .. 3*C) (stats then holds 3*C floats); mvp_bn_running_update applies the update later.
                            For forwards that run concurrently on several streams (mvp/pipeline.py): the running statistics are the only
                            state a frozen forward mutates, and their momentum updates must happen in batch order.                     */
+  /* --- several batches in one launch (groups = G > 1; mvp/pipeline.py stacks G equal batches into one frozen forward): x holds
+   * G * B images; statistics, normalisation and outputs are those of each batch of B images ALONE (train-mode BatchNorm is per batch,
+   * dino.py:185-191) — the same bits as G separate calls.  Group g reads x + g * B*N*C and writes stats + g * stats_gstride,
+   * nchw + g * nchw_gstride, tok_* + g * tok_gstride, cls_out + g * cls_gstride (strides in elements).  Train mode needs
+   * defer_running = 1 (the running statistics are then updated per batch by mvp_bn_running_update, in batch order); tokT_* is not
+   * supported; workspace_bytes >= G * mvp_bn_tokens_workspace_bytes(B * N, C).  groups <= 1: one batch, the strides are ignored.     */
+  int groups;
+  int64_t stats_gstride, nchw_gstride, tok_gstride, cls_gstride;
 } mvp_bn_tokens_args;
 int64_t mvp_bn_tokens_workspace_bytes(int M, int C);
 int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args*, void* stream);

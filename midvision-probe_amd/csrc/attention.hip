@@ -189,14 +189,21 @@ __device__ __forceinline__ void attn_store(AttnState<SPLIT>& st, const mvp_atten
     const float inv = 1.0f / l;
     const int qrow = q0 + qt * 16 + c16;
     if (qrow >= p.N) continue;
-    const size_t ob = (rowbase + qrow) * p.ld_out + h * 64 + g * 4;
+    const bool ilv = p.out_layout == MVP_PAIR_A_ILV32;  // one array, hi | lo interleaved per 32 columns (column h*64 + dt*16 + g*4)
+    const size_t ob = (rowbase + qrow) * p.ld_out + (ilv ? h * 128 : h * 64) + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint32_t h01, l01, h23, l23;
       split2_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
       split2_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
-      *(u32x2_t*)(p.out_hi + ob + dt * 16) = u32x2_t{h01, h23};
-      if (p.out_lo) *(u32x2_t*)(p.out_lo + ob + dt * 16) = u32x2_t{l01, l23};
+      if (ilv) {
+        const size_t o = ob + (dt >> 1) * 64 + (dt & 1) * 16;
+        *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
+        *(u32x2_t*)(p.out_hi + o + 32) = u32x2_t{l01, l23};
+      } else {
+        *(u32x2_t*)(p.out_hi + ob + dt * 16) = u32x2_t{h01, h23};
+        if (p.out_lo) *(u32x2_t*)(p.out_lo + ob + dt * 16) = u32x2_t{l01, l23};
+      }
     }
   }
 }
@@ -322,8 +329,9 @@ extern "C" int mvp_attention_fwd(const mvp_attention_args* a, void* stream) {
   if (!a || !a->qkv_hi || !a->out_hi) return MVP_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->H <= 0) return MVP_EINVAL;
   if ((a->ld_qkv & 7) || (a->ld_out & 3) || a->ld_qkv < 3 * a->H * 64 || a->ld_out < a->H * 64) return MVP_EINVAL;
+  if (a->out_layout != MVP_PAIR_SEPARATE && (a->out_layout != MVP_PAIR_A_ILV32 || a->precision != MVP_PREC_BF16X3 || a->ld_out < 2 * a->H * 64)) return MVP_EINVAL;
   if (a->precision == MVP_PREC_BF16X3) {
-    if (!a->qkv_lo || !a->out_lo) return MVP_EINVAL;
+    if (!a->qkv_lo || (!a->out_lo && a->out_layout == MVP_PAIR_SEPARATE)) return MVP_EINVAL;
     return launch_attention<3>(a, (hipStream_t)stream);
   }
   if (a->precision != MVP_PREC_BF16) return MVP_EINVAL;

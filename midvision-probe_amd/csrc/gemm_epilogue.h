@@ -181,8 +181,14 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
         uint32_t h01, l01, h23, l23;
         split2_bf16(v[0], v[1], h01, l01);
         split2_bf16(v[2], v[3], h23, l23);
-        const size_t o = (size_t)orow * p.ldob + ncol;
-        if (vec_ok && ((p.ldob & 3) == 0)) {
+        const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;  // one array, hi | lo interleaved per 32 columns (N % 32 == 0: host check)
+        const size_t o = (size_t)orow * p.ldob + (oilv ? ilv32_col(ncol) : ncol);
+        if (oilv) {
+          if (ncol < p.N) {
+            *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
+            *(u32x2_t*)(p.out_hi + o + 32) = u32x2_t{l01, l23};
+          }
+        } else if (vec_ok && ((p.ldob & 3) == 0)) {
           *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
           if (p.out_lo) *(u32x2_t*)(p.out_lo + o) = u32x2_t{l01, l23};
         } else {

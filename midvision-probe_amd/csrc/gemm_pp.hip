@@ -329,6 +329,7 @@ extern "C" int mvp_gemm_pp(const mvp_gemm_args* a, void* stream) {
   if (a->M <= 0 || a->N <= 0 || a->K < 64 || (a->K & 31) || a->conv || a->splitk > 1) return MVP_EINVAL;
   if ((a->lda & 7) || (a->ldw & 7) || a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
+  if (a->out_pair_layout != MVP_PAIR_SEPARATE && (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31))) return MVP_EINVAL;
   // 32-bit per-lane byte offsets: 256 tile rows of the widest supported row must stay below 2 GiB
   if ((int64_t)256 * a->lda * 2 >= 0x7fffff00ll || (int64_t)256 * a->ldw * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;

@@ -370,6 +370,7 @@ extern "C" int64_t mvp_gemm_streamk_workspace_bytes(void) {
 
 // Called by mvp_gemm_bias_act_res when splitk == MVP_GEMM_STREAMK.
 extern "C" int mvp_gemm_streamk(const mvp_gemm_args* a, void* stream) {
+  if (a && (a->pair_layout != MVP_PAIR_SEPARATE || a->out_pair_layout != MVP_PAIR_SEPARATE)) return MVP_EINVAL;  // separate hi / lo arrays only
   if (!a || !a->a_hi || !a->w_hi || a->M <= 0 || a->N <= 0 || a->K <= 0 || (a->K & 63)) return MVP_EINVAL;
   if (a->conv || a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) return MVP_EINVAL;
   if ((a->lda & 7) || (a->ldw & 7) || (!a->out_f32 && !a->out_hi)) return MVP_EINVAL;

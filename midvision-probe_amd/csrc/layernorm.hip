@@ -59,8 +59,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
       uint32_t h[4], l[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) split2_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
-      *(u32x4_t*)(p.out_hi + o) = u32x4_t{h[0], h[1], h[2], h[3]};
-      if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{l[0], l[1], l[2], l[3]};
+      if (p.out_layout == MVP_PAIR_A_ILV32) {  // one array, hi | lo interleaved per 32 columns (an 8-element chunk never straddles a block)
+        const size_t oi = (size_t)row * 2 * p.C + ilv32_col(c * 8);
+        *(u32x4_t*)(p.out_hi + oi) = u32x4_t{h[0], h[1], h[2], h[3]};
+        *(u32x4_t*)(p.out_hi + oi + 32) = u32x4_t{l[0], l[1], l[2], l[3]};
+      } else {
+        *(u32x4_t*)(p.out_hi + o) = u32x4_t{h[0], h[1], h[2], h[3]};
+        if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{l[0], l[1], l[2], l[3]};
+      }
       if (p.out_f32) {
         *(float4*)(p.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);
         *(float4*)(p.out_f32 + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
 extern "C" int mvp_layernorm_fwd(const mvp_layernorm_args* a, void* stream) {
   if (!a || !a->x || !a->gamma || !a->beta || !a->out_hi) return MVP_EINVAL;
   if (a->M <= 0 || a->C <= 0 || (a->C & 7) || a->C > 64 * 8 * LN_MAXV) return MVP_EINVAL;
+  if (a->out_layout != MVP_PAIR_SEPARATE && (a->out_layout != MVP_PAIR_A_ILV32 || (a->C & 31))) return MVP_EINVAL;
   hipLaunchKernelGGL(layernorm_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;

@@ -42,6 +42,9 @@ __device__ __forceinline__ uint32_t pack2(uint16_t a, uint16_t b) {
   return (uint32_t)a | ((uint32_t)b << 16);
 }
 
+// Column c of a hi|lo-interleaved pair array (MVP_PAIR_*_ILV32): element offset of the hi half inside the row; the lo half sits 32 further.
+__device__ __forceinline__ int ilv32_col(int c) { return ((c >> 5) << 6) | (c & 31); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

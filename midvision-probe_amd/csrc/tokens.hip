@@ -88,6 +88,8 @@ __host__ __device__ inline int bn_slab_rows(int M) {
 // Pass 1: per slab and channel, shifted sums (shift = first row of the slab) so that the later variance is free of
 // catastrophic cancellation even when |mean| >> std.
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int C, int rb) {
+  x += (size_t)blockIdx.z * M * C;                      // batch blockIdx.z of a grouped call: its own rows,
+  part += (size_t)blockIdx.z * gridDim.x * C * 3;       // its own partials
   const int r0 = blockIdx.x * rb;
   const int nr = min(rb, M - r0);
   const int c = blockIdx.y * 256 + threadIdx.x;
@@ -126,9 +128,12 @@ __device__ __forceinline__ float bn_running(float old, float val, float momentum
   return a + b;
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const mvp_bn_tokens_args p, const float* __restrict__ part,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(mvp_bn_tokens_args p, const float* __restrict__ part,
                                                            float* __restrict__ ss, int M, int nslab, int rb) {
   __shared__ double red[BN_FG][BN_FC][2];
+  part += (size_t)blockIdx.y * nslab * p.C * 3;  // batch blockIdx.y of a grouped call
+  ss += (size_t)blockIdx.y * 2 * p.C;
+  p.stats += (size_t)blockIdx.y * p.stats_gstride;
   const int lc = threadIdx.x & (BN_FC - 1), grp = threadIdx.x / BN_FC;
   const int c = blockIdx.x * BN_FC + lc;
   const bool ok = c < p.C;
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const mvp_bn_run
 __global__ __launch_bounds__(256) void bn_prep_kernel(const mvp_bn_tokens_args p, float* __restrict__ ss) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= p.C) return;
+  ss += (size_t)blockIdx.y * 2 * p.C;  // (every batch of a grouped call gets the same eval-mode / identity scale and shift)
   if (p.mode == 2) {
     ss[c] = 1.f; ss[p.C + c] = 0.f;
     return;
@@ -208,8 +214,17 @@ __global__ __launch_bounds__(256) void bn_prep_kernel(const mvp_bn_tokens_args p
 
 // Pass 3: y = x*scale + shift on the spatial tokens; 32-token x 64-channel tiles go through
 // LDS so that both the token-major reads and the NCHW / transposed writes are coalesced.
-__global__ __launch_bounds__(256) void bn_apply_kernel(const mvp_bn_tokens_args p, const float* __restrict__ ss) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(mvp_bn_tokens_args p, const float* __restrict__ ss) {
   __shared__ float tile[32][65];
+  if (blockIdx.z) {  // batch blockIdx.z of a grouped call: its rows, its scale / shift, its outputs
+    const size_t g = blockIdx.z;
+    p.x += g * p.B * p.N * p.C;
+    ss += g * 2 * p.C;
+    if (p.nchw) p.nchw += g * p.nchw_gstride;
+    if (p.tok_hi) p.tok_hi += g * p.tok_gstride;
+    if (p.tok_lo) p.tok_lo += g * p.tok_gstride;
+    if (p.cls_out) p.cls_out += g * p.cls_gstride;
+  }
   const int t = threadIdx.x;
   const int ptiles = (p.hw + 31) / 32;
   const int b = blockIdx.x / ptiles, pt = blockIdx.x - b * ptiles;
@@ -338,25 +353,30 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
   if (!a || !a->x || !a->workspace) return MVP_EINVAL;
   if (a->B <= 0 || a->N <= 0 || a->C <= 0 || a->hw <= 0 || a->hw > a->N) return MVP_EINVAL;
   const int M = a->B * a->N;
-  if (a->workspace_bytes < mvp_bn_tokens_workspace_bytes(M, a->C)) return MVP_EINVAL;
+  const int G = a->groups > 1 ? a->groups : 1;
+  if (a->workspace_bytes < G * mvp_bn_tokens_workspace_bytes(M, a->C)) return MVP_EINVAL;
   if (a->mode == 0 && !a->stats) return MVP_EINVAL;
   if (a->defer_running && a->mode != 0) return MVP_EINVAL;
   if (a->mode == 1 && (!a->running_mean || !a->running_var)) return MVP_EINVAL;
+  if (G > 1) {  // per-batch statistics of a grouped call: running statistics only through the deferred update, no transposed packing
+    if ((a->mode == 0 && !a->defer_running) || a->tokT_hi || G > 65535) return MVP_EINVAL;
+    if (a->stats_gstride < 0 || a->nchw_gstride < 0 || a->tok_gstride < 0 || a->cls_gstride < 0) return MVP_EINVAL;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int rb = bn_slab_rows(M);
   const int nslab = (M + rb - 1) / rb;
   float* part = (float*)a->workspace;
-  float* ss = part + (size_t)nslab * a->C * 3;
+  float* ss = part + (size_t)G * nslab * a->C * 3;  // [G][2 * C] scale / shift behind the partials of all batches
   if (a->mode == 0) {
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab, (a->C + 255) / 256), dim3(256), 0, s, a->x, part, M, a->C, rb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + BN_FC - 1) / BN_FC), dim3(1024), 0, s, *a, part, ss, M, nslab, rb);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab, (a->C + 255) / 256, G), dim3(256), 0, s, a->x, part, M, a->C, rb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a->C + BN_FC - 1) / BN_FC, G), dim3(1024), 0, s, *a, part, ss, M, nslab, rb);
   } else {
-    hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256), dim3(256), 0, s, *a, ss);
+    hipLaunchKernelGGL(bn_prep_kernel, dim3((a->C + 255) / 256, G), dim3(256), 0, s, *a, ss);
   }
   if (a->cls_out && a->N <= a->hw) return MVP_EINVAL;
   if (a->nchw || a->tok_hi || a->tokT_hi || a->cls_out) {
     const int ptiles = (a->hw + 31) / 32;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(a->B * ptiles, (a->C + 63) / 64), dim3(256), 0, s, *a, ss);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(a->B * ptiles, (a->C + 63) / 64, G), dim3(256), 0, s, *a, ss);
   }
   MVP_LAUNCH_CHECK();
   return MVP_OK;

@@ -54,17 +54,17 @@ class GemmArgs(C.Structure):
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
                 ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64),
-                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i), ("pair_layout", _i)]
+                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i), ("pair_layout", _i), ("out_pair_layout", _i)]
 
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("x", _vp), ("gamma", _vp), ("beta", _vp), ("out_hi", _vp), ("out_lo", _vp), ("out_f32", _vp),
-                ("M", _i), ("C", _i), ("eps", _f)]
+                ("M", _i), ("C", _i), ("eps", _f), ("out_layout", _i)]
 
 
 class AttentionArgs(C.Structure):
     _fields_ = [("qkv_hi", _vp), ("qkv_lo", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("N", _i), ("H", _i),
-                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i)]
+                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i), ("out_layout", _i)]
 
 
 class ClsRowsArgs(C.Structure):
@@ -77,7 +77,7 @@ class BnTokensArgs(C.Structure):
                 ("tokT_hi", _vp), ("tokT_lo", _vp), ("ldT", _i),
                 ("workspace", _vp), ("workspace_bytes", _i64),
                 ("B", _i), ("N", _i), ("C", _i), ("hw", _i), ("eps", _f), ("momentum", _f), ("mode", _i), ("cls_out", _vp), ("num_batches_tracked", _vp),
-                ("defer_running", _i)]
+                ("defer_running", _i), ("groups", _i), ("stats_gstride", _i64), ("nchw_gstride", _i64), ("tok_gstride", _i64), ("cls_gstride", _i64)]
 
 
 class BnRunningUpdateArgs(C.Structure):

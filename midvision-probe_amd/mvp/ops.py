@@ -16,6 +16,23 @@ from .lib import PREC_BF16, PREC_BF16X3
 
 Pair = Tuple[torch.Tensor, Optional[torch.Tensor]]
 
+
+class IlvPair:
+    """A bf16 pair stored as ONE array, hi | lo interleaved per 32 columns (MVP_PAIR_A_ILV32, include/mvp_hip.h): ``t`` is
+    [rows, 2 * cols] bf16.  LayerNorm, attention and the GEMM epilogue write it, the large-M GEMM kernel reads it as its A operand
+    (a 32-deep k-step of a row is then one whole 128-byte line)."""
+
+    def __init__(self, rows: int, cols: int, device):
+        if cols % 32:
+            raise lib.MvpError("an interleaved pair needs cols % 32 == 0")
+        self.rows, self.cols = rows, cols
+        self.t = torch.empty(rows, 2 * cols, dtype=torch.bfloat16, device=device)
+
+    def separate(self) -> Pair:
+        """The same values as two [rows, cols] arrays (tests)."""
+        v = self.t.view(self.rows, self.cols // 32, 2, 32)
+        return v[:, :, 0].reshape(self.rows, self.cols).contiguous(), v[:, :, 1].reshape(self.rows, self.cols).contiguous()
+
 # Optional per-launch timing hook used by bench.py's roofline leg: when a list is installed,
 # every GEMM / attention launch is bracketed by HIP events recorded on the launch stream.
 _TRACE = None
@@ -167,6 +184,11 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``.
     streamk: None = automatic (streamk_auto), True / False force the stream-K kernel on / off.
     w_ilv: the same weights as ``interleave_pair(w)``; handed to the large-M kernel when the dispatch rule picks it."""
+    a_ilv, o_ilv = isinstance(a, IlvPair), isinstance(out, IlvPair)
+    if a_ilv:
+        a, lda = (a.t, None), (lda if lda is not None else 2 * K)
+    if o_ilv:
+        out, ldob = (out.t, None), (ldob if ldob is not None else 2 * N)
     o_hi, o_lo = out if out is not None else (None, None)
     args = lib.GemmArgs(
         lib.ptr(a[0]), lib.ptr(a[1]), lib.ptr(w[0]), lib.ptr(w[1]), lib.ptr(bias), lib.ptr(residual),
@@ -176,24 +198,31 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
         act, precision, row_group, row_group_stride, row_group_off, res_row_mod)
     args.act_after_res = int(act_after_res)
     args.tile_policy = pipeline.tile_policy()
+    args.pair_layout = lib.PAIR_A_ILV32 if a_ilv else lib.PAIR_SEPARATE  # (an interleaved A operand always goes to the large-M kernel)
+    args.out_pair_layout = lib.PAIR_A_ILV32 if o_ilv else lib.PAIR_SEPARATE
     if out_mask is not None:
         args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
     if residual_pair is not None:
         args.residual_hi, args.residual_lo = lib.ptr(residual_pair[0]), lib.ptr(residual_pair[1])
     S = 1
     plain = out_mask is None and not act_after_res and residual_pair is None
-    use_sk = plain and splitk is None and (streamk_auto(M, N, K, precision) if streamk is None else bool(streamk))
+    if (a_ilv or o_ilv) and (not plain or splitk not in (None, 1) or streamk):
+        raise lib.MvpError("interleaved pair operands: plain GEMMs only (no masks, split-K or stream-K)")
+    use_sk = plain and not (a_ilv or o_ilv) and splitk is None and (streamk_auto(M, N, K, precision) if streamk is None else bool(streamk))
     if use_sk:
         ws = _streamk_workspace(a[0].device)
         args.splitk, args.splitk_ws, args.splitk_ws_bytes = -1, lib.ptr(ws), ws.numel()
-    elif plain:
+    elif plain and not a_ilv:
         S = splitk_auto(M, N, K) if splitk is None else int(splitk)
     if S > 1:
         ws = _splitk_workspace(M, N, S, a[0].device)
         args.splitk, args.splitk_ws, args.splitk_ws_bytes = S, lib.ptr(ws), ws.numel()
-    tile = gemm_tile(M, N, K, precision, S, args.tile_policy) if (w_ilv is not None or _TRACE is not None) else ""
+    tile = gemm_tile(M, N, K, precision, S, args.tile_policy) if (w_ilv is not None or _TRACE is not None) and not a_ilv else ""
+    if a_ilv:
+        tile = "pp 256, 256, 32, 3"
     if w_ilv is not None and plain and not use_sk and S <= 1 and tile.startswith("pp ") and ldw is None:
-        args.w_hi, args.w_lo, args.ldw, args.pair_layout = lib.ptr(w_ilv), None, 2 * K, lib.PAIR_W_ILV32
+        args.w_hi, args.w_lo, args.ldw = lib.ptr(w_ilv), None, 2 * K
+        args.pair_layout |= lib.PAIR_W_ILV32
     if _TRACE is None:
         lib.call("mvp_gemm_bias_act_res", args)
         return
@@ -206,15 +235,23 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,
               out_f32: Optional[torch.Tensor] = None) -> None:
-    a = lib.LayerNormArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(out[0]), lib.ptr(out[1]), lib.ptr(out_f32), M, Cdim, eps)
+    ilv = isinstance(out, IlvPair)
+    if ilv:
+        out = (out.t, None)
+    a = lib.LayerNormArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(out[0]), lib.ptr(out[1]), lib.ptr(out_f32), M, Cdim, eps,
+                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE)
     # algorithmic HBM bytes: the fp32 row read once + the bf16 pair (or single bf16) written once
-    nb = M * Cdim * (4 + 2 * (2 if out[1] is not None else 1) + (4 if out_f32 is not None else 0))
+    nb = M * Cdim * (4 + 2 * (2 if (ilv or out[1] is not None) else 1) + (4 if out_f32 is not None else 0))
     _traced("hbm", "layernorm_kernel", 0, float(nb), lambda: lib.call("mvp_layernorm_fwd", a))
 
 
 def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None) -> None:
+    ilv = isinstance(out, IlvPair)
+    if ilv:
+        out, ld_out = (out.t, None), (ld_out if ld_out is not None else 2 * H * 64)
     a = lib.AttentionArgs(lib.ptr(qkv[0]), lib.ptr(qkv[1]), lib.ptr(out[0]), lib.ptr(out[1]), B, N, H,
-                          ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision)
+                          ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision,
+                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE)
     if _TRACE is None:
         lib.call("mvp_attention_fwd", a)
         return
@@ -235,17 +272,22 @@ def bn_tokens_workspace_bytes(M: int, Cdim: int) -> int:
 
 def bn_tokens_to_nchw(x, B, N, Cdim, hw, *, workspace, stats=None, gamma=None, beta=None, running_mean=None, running_var=None,
                       nchw=None, tok: Optional[Pair] = None, ld_tok=0, col_off=0, tokT: Optional[Pair] = None, ldT=0,
-                      eps=1e-5, momentum=0.1, mode=0, cls_out=None, num_batches_tracked=None, defer_running=False) -> None:
+                      eps=1e-5, momentum=0.1, mode=0, cls_out=None, num_batches_tracked=None, defer_running=False,
+                      groups=1, stats_gstride=0, nchw_gstride=0, tok_gstride=0, cls_gstride=0) -> None:
     """``defer_running`` (mode 0): the running statistics and the step counter are left alone, ``stats`` ([3*C]) also receives the
-    unbiased variance, and ``bn_running_update`` applies the momentum update later (forwards in flight on several streams)."""
+    unbiased variance, and ``bn_running_update`` applies the momentum update later (forwards in flight on several streams).
+    ``groups`` = G > 1: ``x`` holds G stacked batches of B images; every batch is normalised with its own statistics in the same three
+    launches, outputs at the given element strides between batches (mvp_bn_tokens_args.groups)."""
     t_hi, t_lo = tok if tok is not None else (None, None)
     tt_hi, tt_lo = tokT if tokT is not None else (None, None)
     a = lib.BnTokensArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(running_mean), lib.ptr(running_var), lib.ptr(stats),
                          lib.ptr(nchw), lib.ptr(t_hi), lib.ptr(t_lo), ld_tok, col_off, lib.ptr(tt_hi), lib.ptr(tt_lo), ldT,
                          lib.ptr(workspace), workspace.numel() * workspace.element_size(), B, N, Cdim, hw, eps, momentum, mode, lib.ptr(cls_out),
-                         lib.ptr(num_batches_tracked) if mode == 0 else None, int(bool(defer_running) and mode == 0))
+                         lib.ptr(num_batches_tracked) if mode == 0 else None, int(bool(defer_running) and mode == 0),
+                         int(groups), int(stats_gstride), int(nchw_gstride), int(tok_gstride), int(cls_gstride))
     # algorithmic HBM bytes: x read twice in train mode (statistics, apply), NCHW fp32 + token-major pair written
-    M = B * N
+    M = B * N * max(1, int(groups))
+    B = B * max(1, int(groups))
     nb = M * Cdim * 4 * (2 if mode == 0 else 1) + B * hw * Cdim * ((4 if nchw is not None else 0) + (4 if tok is not None and tok[1] is not None else (2 if tok is not None else 0)))
     _traced("hbm", "bn_tokens (partial+finalize+apply)", 0, float(nb), lambda: lib.call("mvp_bn_tokens_to_nchw_fwd", a))
 

@@ -15,6 +15,7 @@ the returned NCHW maps.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -49,17 +50,24 @@ class PackedFeatures:
     """Token-major operand of the linear-probe GEMMs: F [Mpad, Cpad] bf16 pair (forward: F·Wᵀ by the NT GEMM;
     weight gradient: gᵀ·F by the TN split-K kernel, which reads the same row-major image through transposed LDS reads)."""
 
-    def __init__(self, B, h, w, Ctot, precision, device):
+    def __init__(self, B, h, w, Ctot, precision, device, tok=None):
         self.B, self.h, self.w, self.Ctot, self.precision = B, h, w, Ctot, precision
         self.M = B * h * w
-        self.Mpad = (self.M + 63) // 64 * 64
-        self.Cpad = (Ctot + 127) // 128 * 128  # NT GEMM K % 64, TN kernel Cin % 128; pad columns stay zero
-        self.tok = ops.zeros_pair((self.Mpad, self.Cpad), precision, device)
+        self.Mpad, self.Cpad = self.padded(B, h, w, Ctot)
+        # ``tok``: a zero-initialised [Mpad, Cpad] pair owned by the caller (the batches of a grouped forward share one allocation)
+        self.tok = tok if tok is not None else ops.zeros_pair((self.Mpad, self.Cpad), precision, device)
         self.sources: List[Tuple[int, int]] = []  # (data_ptr, _version) of the NCHW maps packed here
         self.source_refs: List[torch.Tensor] = []  # the maps themselves: while they live, their addresses cannot be recycled
         self.generation = 0  # bumped every time the buffers are rewritten (they are reused across steps)
         self.scratch: Dict[str, object] = {}  # per-shape scratch of the head backward (zero-padded once)
 
+
+def _padded(B, h, w, Ctot):
+    """(Mpad, Cpad) of a packing: NT GEMM K % 64, TN kernel Cin % 128; pad rows / columns stay zero."""
+    return (B * h * w + 63) // 64 * 64, (Ctot + 127) // 128 * 128
+
+
+PackedFeatures.padded = staticmethod(_padded)
 
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
 _PACK_REGISTRY_MAX = 64  # one entry per (pipeline slot, batch of a grouped forward)
@@ -150,14 +158,18 @@ class ViTEngine:
             N = 1 + gh * gw
             M = B * N
             C, dev, pr = self.C, self.device, self.precision
+            # When every GEMM of a block goes to the large-M kernel (M fills whole rounds of 256x256 tiles: grouped forwards), its A
+            # operands — LayerNorm output, attention output, fc1 output — are kept as hi|lo-interleaved arrays (ops.IlvPair): a 32-deep
+            # k-step of a row is then one whole 128-byte line for the LDS-DMA (2-3 % per GEMM on top of the interleaved weights).
+            ilv = (pr == PREC_BF16X3 and os.environ.get("MVP_ILV", "1") != "0" and C % 32 == 0 and self.hidden % 32 == 0 and
+                   all(ops.gemm_tile(M, n, k, pr, 1, pipeline.tile_policy()).startswith("pp ") for n, k in ((3 * C, C), (C, C), (self.hidden, C), (C, self.hidden))))
             ws = dict(
                 x=torch.empty(M, C, dtype=torch.float32, device=dev),
-                xn=ops.empty_pair((M, C), pr, dev),
+                xn=ops.IlvPair(M, C, dev) if ilv else ops.empty_pair((M, C), pr, dev),
                 qkv=ops.empty_pair((M, 3 * C), pr, dev),
-                ao=ops.empty_pair((M, C), pr, dev),
-                hmid=ops.empty_pair((M, self.hidden), pr, dev),
+                ao=ops.IlvPair(M, C, dev) if ilv else ops.empty_pair((M, C), pr, dev),
+                hmid=ops.IlvPair(M, self.hidden, dev) if ilv else ops.empty_pair((M, self.hidden), pr, dev),
                 patches=ops.empty_pair((B * gh * gw, self.in_chans * self.patch * self.patch), pr, dev),
-                bn_ws=torch.empty(ops.bn_tokens_workspace_bytes(M, C) // 4 + 16, dtype=torch.float32, device=dev),
             )
             self._ws = {k: v for k, v in self._ws.items() if k[:3] == key[:3]}  # keep one resolution resident (one buffer set per slot)
             self._ws[key] = ws
@@ -167,8 +179,8 @@ class ViTEngine:
         """Every buffer set this engine currently keeps for pipeline slot ``slot`` (activation workspaces, feature packings, output
         maps).  A captured hipGraph of that slot's forward holds their raw addresses: the pipeline keeps this list alive with the
         graph, because the engine itself drops the buffers of other resolutions when a new one arrives."""
-        return ([v for k, v in self._ws.items() if k[-1] == slot] + [v for k, v in self._packs.items() if k[-2] == slot]
-                + [v for k, v in self._slot_outs.items() if k[-2] == slot] + list(self._pos.values()))
+        return ([v for k, v in self._ws.items() if k[-1] == slot] + [v for k, v in self._packs.items() if k[-1] == slot]
+                + [v for k, v in self._slot_outs.items() if k[-1] == slot] + list(self._pos.values()))
 
     def pos_for(self, gh: int, gw: int, dim2: int, dim3: int) -> torch.Tensor:
         """Pos-embed for a gh x gw grid.  'dino': bicubic resize with the +0.1 scale nudge of
@@ -248,33 +260,40 @@ class ViTEngine:
         N, C, hw = 1 + gh * gw, self.C, gh * gw
         layers = list(layers)
         outs_g = [TapOutputs() for _ in range(G)]
+        bn_ws = ws.get(("bn_ws", G))  # tap-BN partials + scale / shift of G batches of B * N rows
+        if bn_ws is None:
+            bn_ws = ws[("bn_ws", G)] = torch.empty(G * ops.bn_tokens_workspace_bytes(B * N, C) // 4 + 16, dtype=torch.float32, device=self.device)
         packed_g = [None] * G
         if pack:  # reuse the (zero padded) packing buffers across steps: only the valid region is rewritten
+            pkey = (B, gh, gw, len(layers), G, pipeline.current_slot())
+            packs = self._packs.get(pkey)
+            if packs is None:
+                Mpad, Cpad = PackedFeatures.padded(B, gh, gw, C * len(layers))
+                big = ops.zeros_pair((G, Mpad, Cpad), self.precision, self.device)  # one allocation: the tap kernel writes all batches in one launch
+                packs = [PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device,
+                                        tok=(big[0][g], big[1][g] if big[1] is not None else None)) for g in range(G)]
+                self._packs = {k: v for k, v in self._packs.items() if k[:4] == pkey[:4]}
+                self._packs[pkey] = packs
             for g in range(G):
-                pkey = (B, gh, gw, len(layers), pipeline.current_slot(), g)
-                packed = self._packs.get(pkey)
-                if packed is None:
-                    packed = PackedFeatures(B, gh, gw, C * len(layers), self.precision, self.device)
-                    self._packs = {k: v for k, v in self._packs.items() if k[:4] == pkey[:4]}
-                    self._packs[pkey] = packed
-                packed.generation += 1
-                packed_g[g] = packed
+                packs[g].generation += 1
+            packed_g = list(packs)
         # Plain calls return freshly allocated maps (the caller may keep them).  A pipelined forward (mvp/pipeline.py) writes into
         # buffers owned by its slot instead — valid until the slot's next forward, which is the pipeline's contract — so the
         # steady state allocates nothing and no block ever changes hands between the side stream's and the trainer's allocator pools.
-        slot_out_g = [None] * G
+        def new_out():
+            return dict(stats=torch.empty(G, len(layers), 3 * C, dtype=torch.float32, device=self.device),
+                        nchw=[torch.empty(G, B, C, gh, gw, dtype=torch.float32, device=self.device) for _ in layers],
+                        cls=[torch.empty(G, B, C, dtype=torch.float32, device=self.device) if want_cls else None for _ in layers])
+
         if pipeline.pipelined():
-            for g in range(G):
-                okey = (B, gh, gw, tuple(layers), bool(want_cls), pipeline.current_slot(), g)
-                slot_out = self._slot_outs.get(okey)
-                if slot_out is None:
-                    slot_out = dict(stats=torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device),
-                                    nchw=[torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device) for _ in layers],
-                                    cls=[torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None for _ in layers])
-                    self._slot_outs = {k: v for k, v in self._slot_outs.items() if k[:5] == okey[:5]}
-                    self._slot_outs[okey] = slot_out
-                slot_out_g[g] = slot_out
-        stats_g = [so["stats"] if so else torch.empty(len(layers), 3 * C, dtype=torch.float32, device=self.device) for so in slot_out_g]
+            okey = (B, gh, gw, tuple(layers), bool(want_cls), G, pipeline.current_slot())
+            out = self._slot_outs.get(okey)
+            if out is None:
+                out = new_out()
+                self._slot_outs = {k: v for k, v in self._slot_outs.items() if k[:5] == okey[:5]}
+                self._slot_outs[okey] = out
+        else:
+            out = new_out()
         for o in outs_g:
             o.cls = []
 
@@ -286,27 +305,25 @@ class ViTEngine:
             raise lib.MvpError("a grouped forward with train-mode tap BN must run under the pipeline (its running-statistics updates are per batch)")
 
         def tap(j):
+            b = bn[j] if bn is not None else None
+            nchw, cls = out["nchw"][j], out["cls"][j]
+            tok0 = packed_g[0].tok if pack else None
+            # ONE call for all batches of the group: statistics, normalisation and outputs per batch (mvp_bn_tokens_args.groups)
+            ops.bn_tokens_to_nchw(
+                ws["x"], B, N, C, hw, workspace=bn_ws, stats=out["stats"][0, j],
+                gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
+                running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
+                nchw=nchw[0], tok=tok0, ld_tok=packed_g[0].Cpad if pack else 0, col_off=j * C,
+                mode=bn_mode, cls_out=cls[0] if want_cls else None, num_batches_tracked=b.get("num_batches_tracked") if b else None, defer_running=defer,
+                groups=G, stats_gstride=out["stats"].stride(0), nchw_gstride=nchw.stride(0),
+                tok_gstride=(packed_g[0].Mpad * packed_g[0].Cpad) if pack else 0, cls_gstride=cls.stride(0) if want_cls else 0)
             for g in range(G):
-                slot_out, packed, outs = slot_out_g[g], packed_g[g], outs_g[g]
-                if slot_out:
-                    nchw, cls = slot_out["nchw"][j], slot_out["cls"][j]
-                else:
-                    nchw = torch.empty(B, C, gh, gw, dtype=torch.float32, device=self.device)
-                    cls = torch.empty(B, C, dtype=torch.float32, device=self.device) if want_cls else None
                 if want_cls:
-                    outs.cls.append(cls)
-                b = bn[j] if bn is not None else None
-                xg = ws["x"] if G == 1 else ws["x"][g * B * N:(g + 1) * B * N]  # this batch's rows of the residual stream
-                ops.bn_tokens_to_nchw(
-                    xg, B, N, C, hw, workspace=ws["bn_ws"], stats=stats_g[g][j],
-                    gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
-                    running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
-                    nchw=nchw, tok=packed.tok if packed else None, ld_tok=packed.Cpad if packed else 0, col_off=j * C,
-                    mode=bn_mode, cls_out=cls, num_batches_tracked=b.get("num_batches_tracked") if b else None, defer_running=defer)
+                    outs_g[g].cls.append(cls[g])
                 if defer and b is not None and b.get("running_mean") is not None:
-                    st = stats_g[g][j]
+                    st = out["stats"][g, j]
                     pipeline.defer(lambda st=st, b=b: ops.bn_running_update(st, b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C), group=g)
-                outs.append(nchw)
+                outs_g[g].append(nchw[g])
 
         for i in range(self.depth):
             if tap_input_of_block and i in layers:
@@ -319,7 +336,7 @@ class ViTEngine:
                 if len(outs_g[0]) == len(layers):
                     break
         for g in range(G):
-            outs_g[g].stats = stats_g[g]
+            outs_g[g].stats = out["stats"][g]
             if packed_g[g] is not None:
                 outs_g[g].packed = packed_g[g]
                 register_pack(outs_g[g], packed_g[g])

@@ -393,3 +393,114 @@ def test_vit_base_480x640_vs_reference_golden(dev):
     for i in range(4):
         idx = torch.from_numpy(g[f"b480x640_idx{i}"])
         assert rel_l2(taps[i].flatten().cpu()[idx].numpy(), g[f"b480x640_tap{i}_samples"]) < 1e-3, i
+
+
+# ------------------------------------------------------------------------------------------------ round 3: what the bench times
+def _gemm_case(dev, M, N, K, seed):
+    from mvp import lib, ops
+
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ap, wp = ops.split_bf16(a.to(dev), lib.PREC_BF16X3), ops.split_bf16(w.to(dev), lib.PREC_BF16X3)
+    # fp64 reference on the device (the M = 19k cases are 1e11 flops: seconds on the GPU, minutes on the host)
+    ref = (ap[0].double() + ap[1].double()) @ (wp[0].double() + wp[1].double()).t() + bias.to(dev).double()
+    return ap, wp, bias.to(dev), res.to(dev), ref
+
+
+@pytest.mark.parametrize("policy", ["alone", "shared", "pp"])
+@pytest.mark.parametrize("shape", [(3152, 2304, 768), (3152, 768, 768), (3152, 3072, 768), (3152, 768, 3072), (19216, 768, 3072), (18912, 2304, 768)])
+def test_gemm_tile_policies_at_the_timed_shapes_vs_fp64(dev, policy, shape):
+    """Every kernel family the bench can launch for the backbone GEMMs (VERDICT r2 #2a), at the shapes it launches them with:
+    MVP_TILES_ALONE (64x64 family), MVP_TILES_SHARED (128x128, 8 waves) — both with the large-M kernel switched off so that the tile
+    kernels themselves are measured — and mvp_gemm_pp (256x256 ping-pong).  Against fp64 (<= 5e-5 rel-L2) with the fused epilogues the
+    ViT uses (bias; bias + GELU -> pair; bias + residual -> fp32), and all three bit-identical to one another (same k order)."""
+    import ctypes as C
+
+    from mvp import lib, ops
+
+    M, N, K = shape
+    ap, wp, bias, res, ref = _gemm_case(dev, M, N, K, M + N + K)
+    so = lib.load()
+    for act, use_res in ((lib.ACT_NONE, False), (lib.ACT_GELU, False), (lib.ACT_NONE, True)):
+        r = ref
+        if act == lib.ACT_GELU:
+            r = F.gelu(r)
+        if use_res:
+            r = r + res.double()
+        outs = {}
+        for pol in ("alone", policy):
+            out = torch.full((M, N), float("nan"), device=dev)
+            op = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+            a = lib.GemmArgs(lib.ptr(ap[0]), lib.ptr(ap[1]), lib.ptr(wp[0]), lib.ptr(wp[1]), lib.ptr(bias), lib.ptr(res) if use_res else None,
+                             lib.ptr(out), lib.ptr(op[0]), lib.ptr(op[1]), M, N, K, K, K, N, N, N, act, lib.PREC_BF16X3, 0, 0, 0, 0)
+            a.tile_policy = {"alone": lib.TILES_NO_PP, "shared": lib.TILES_SHARED | lib.TILES_NO_PP, "pp": 0}[pol]
+            lib.check((so.mvp_gemm_pp if pol == "pp" else so.mvp_gemm_bias_act_res)(C.byref(a), lib.stream_ptr()), pol)
+            torch.cuda.synchronize()
+            d = out.double() - r
+            assert (d.norm() / r.norm()).item() < 5e-5, (shape, pol, act, use_res)
+            d = op[0].double() + op[1].double() - r
+            assert (d.norm() / r.norm()).item() < 7e-5
+            outs[pol] = (out, op)
+        assert torch.equal(outs[policy][0], outs["alone"][0]) and torch.equal(outs[policy][1][0], outs["alone"][1][0]) and torch.equal(outs[policy][1][1], outs["alone"][1][1])
+
+
+@pytest.mark.parametrize("shape", [(18912, 3072, 768), (5000, 768, 3072), (300, 512, 96)])
+def test_gemm_pp_interleaved_layouts_match_separate(dev, shape):
+    """mvp_gemm_args.pair_layout / out_pair_layout: the large-M kernel on hi|lo-interleaved A and / or W operands, and writing an
+    interleaved output pair, returns exactly the bits it returns on separate arrays (ragged M and N included)."""
+    from mvp import lib, ops
+
+    M, N, K = shape
+    ap, wp, bias, res, ref = _gemm_case(dev, M, N, K, 5 + M)
+    ai = ops.IlvPair(M, K, dev)
+    ai.t.copy_(ops.interleave_pair(ap))
+    wi = ops.interleave_pair(wp)
+    assert torch.equal(ai.separate()[0], ap[0]) and torch.equal(ai.separate()[1], ap[1])
+    base = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+    import os
+
+    os.environ["MVP_GEMM_PP"] = "1"  # (the python-side mirror of the dispatch rule, read per call: hand the interleaved weights over)
+    try:
+        ops.gemm(ap, wp, M, N, K, bias=bias, out=base, act=lib.ACT_GELU, splitk=1)
+        for a_in, w_ilv, o_ilv in ((ai, None, False), (ap, wi, False), (ai, wi, False), (ai, wi, True), (ap, None, True)):
+            if o_ilv:
+                out = ops.IlvPair(M, N, dev)
+                out.t.fill_(float("nan"))
+            else:
+                out = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+            ops.gemm(a_in, wp, M, N, K, bias=bias, out=out, act=lib.ACT_GELU, w_ilv=w_ilv)
+            torch.cuda.synchronize()
+            got = out.separate() if o_ilv else out
+            assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), (shape, type(a_in).__name__, w_ilv is not None, o_ilv)
+    finally:
+        del os.environ["MVP_GEMM_PP"]
+    r = F.gelu(ref)
+    assert ((base[0].double() + base[1].double() - r).norm() / r.norm()).item() < 7e-5
+
+
+def test_layernorm_and_attention_interleaved_outputs_match_separate(dev):
+    """LayerNorm and attention writing their output pair hi|lo-interleaved (the A operand of the large-M GEMM) = the separate pair, bit for bit."""
+    from mvp import lib, ops
+
+    g = torch.Generator().manual_seed(9)
+    M, Cd = 1000, 768
+    x = torch.randn(M, Cd, generator=g).to(dev)
+    gam, bet = torch.randn(Cd, generator=g).to(dev), torch.randn(Cd, generator=g).to(dev)
+    sep = ops.empty_pair((M, Cd), lib.PREC_BF16X3, dev)
+    ilv = ops.IlvPair(M, Cd, dev)
+    ops.layernorm(x, gam, bet, sep, M, Cd, 1e-6)
+    ops.layernorm(x, gam, bet, ilv, M, Cd, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(ilv.separate()[0], sep[0]) and torch.equal(ilv.separate()[1], sep[1])
+    for B, N in ((3, 197), (2, 300)):  # the LDS-resident kernel and the streaming one
+        H = 12
+        qkv = ops.split_bf16(torch.randn(B * N, 3 * H * 64, generator=g).to(dev), lib.PREC_BF16X3)
+        sep = ops.empty_pair((B * N, H * 64), lib.PREC_BF16X3, dev)
+        ilv = ops.IlvPair(B * N, H * 64, dev)
+        ops.attention(qkv, sep, B, N, H, 0.125, lib.PREC_BF16X3)
+        ops.attention(qkv, ilv, B, N, H, 0.125, lib.PREC_BF16X3)
+        torch.cuda.synchronize()
+        assert torch.equal(ilv.separate()[0], sep[0]) and torch.equal(ilv.separate()[1], sep[1]), (B, N)
