@@ -169,10 +169,19 @@ def host_cores() -> int:
     return int(os.environ.get("MVP_CPU_THREADS", min(n, 16)))
 
 
-def flops_per_image(N: int, D: int = 768, depth: int = 12, head_out: int = 256, taps: int = 4) -> float:
+def flops_per_image(N: int, D: int = 768, depth: int = 12, head_out: int = 256, taps: int = 4, probe: str = "linear", hidden: int = 512) -> float:
     """ViT fwd = depth*[N*14,155,776 + 4*N^2*768] + (N-1)*1,179,648; linear head
-    (token resolution, conv1x1 and bilinear commute) fwd + dW = 2 * 2*(N-1)*taps*D*head_out."""
+    (token resolution, conv1x1 and bilinear commute) fwd + dW = 2 * 2*(N-1)*taps*D*head_out.
+    DPT probe (probes.py:215-399): 4 conv1x1 D->hidden at the token grid, 14 conv3x3 hidden->hidden at twice the grid,
+    out_conv 3x3 hidden->hidden and 3x3 hidden->head_out at 8x the grid; backward = bwd-data + bwd-weight of each (no bwd-data
+    into the detached features): ~142 GF forward, ~424 GF per image and step at 224^2."""
     vit = depth * (N * (2 * (3 * D * D + D * D + 8 * D * D)) + 4 * N * N * D) + (N - 1) * 2 * D * D
+    if probe == "dpt":
+        hw = N - 1
+        proj = taps * 2 * hw * D * hidden
+        rcu = 14 * 2 * (4 * hw) * (9 * hidden) * hidden
+        outc = 2 * (64 * hw) * (9 * hidden) * (hidden + head_out)
+        return float(vit + 3 * (proj + rcu + outc) - proj)
     head = 2 * 2 * (N - 1) * taps * D * head_out
     return float(vit + head)
 
@@ -200,9 +209,9 @@ def main():
     warnings.simplefilter("ignore")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
-    if args.pmc_child:  # the profiled child: a few steps of the workload, nothing else
-        args.steps, args.warmup, args.sustained_steps, args.no_cpu_baseline, args.no_roofline, args.no_live_pmc = 4, 2, 0, True, True, True
-        args.inflight = 1  # per-kernel counters: one kernel on the chip at a time
+    if args.pmc_child:  # the profiled child: a few steps of the workload, nothing else (steps are set once the group size is known)
+        args.sustained_steps, args.no_cpu_baseline, args.no_roofline, args.no_live_pmc, args.no_serial_leg = 0, True, True, True, True
+        os.environ["MVP_PIPELINE_GRAPHS"] = "0"  # eager launches: every kernel of the timed run's forwards appears in the trace
     pmc_live = None
     if not (args.no_live_pmc or args.no_roofline) and args.gpus == 1 and "WORLD_SIZE" not in os.environ:
         from mvp.pipeline import SHARED_TILES_FROM, default_depth
@@ -212,10 +221,13 @@ def main():
 
         from mvp.pipeline import MAX_STREAMS
 
-        eff_depth = min(args.inflight if args.inflight is not None else default_depth(_ProbeName), MAX_STREAMS)  # kernel chains side by side
-        # the counters are collected on a serial chain (one kernel on the chip at a time) of the SAME kernel instantiations the timed run launches
-        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe,
-              "--tiles", "shared" if (eff_depth >= SHARED_TILES_FROM or args.tiles == "shared") else "alone"]
+        # the counters are collected on the SAME pipeline configuration the timed run uses (grouped forwards, same kernel instantiations);
+        # the profiler serialises the kernels, so every launch is alone on the chip
+        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe, "--tiles", args.tiles]
+        if args.inflight is not None:
+            wl += ["--inflight", str(args.inflight)]
+        if args.group is not None:
+            wl += ["--group", str(args.group)]
         pmc_live = live_pmc(wl)  # before this process makes any GPU call
     from mvp import dist as mdist
 
@@ -245,18 +257,23 @@ def main():
     # random-init weights of the ViT-B/16 architecture (no network for checkpoints), same on every rank
     vsd = bb.random_vit_state_dict(seed=0)
     model = DINO(return_multilayer=True, add_norm=True, weights=vsd, precision=args.precision).to(dev)
-    torch.manual_seed(0)
-    if args.probe == "linear":
-        probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth",
-                          min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
-    else:
-        probe = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=512,
-                          min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
-    # N > 1: rank 0's probe is broadcast at construction (DDP semantics); the flat-gradient all-reduce of step t runs
-    # under the frozen forward of step t+1 and its AdamW update lands right before the probe forward
-    opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}], overlap_comm=world > 1)
     total_steps = args.warmup + args.steps + 8
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 10 * total_steps, 1.5 * total_steps))
+
+    def make_probe():
+        torch.manual_seed(0)
+        if args.probe == "linear":
+            pr = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth",
+                           min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+        else:
+            pr = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=512,
+                           min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+        # N > 1: rank 0's probe is broadcast at construction (DDP semantics); the flat-gradient all-reduce of step t runs
+        # under the frozen forward of step t+1 and its AdamW update lands right before the probe forward
+        op = FlatAdamW([{"params": pr.parameters(), "lr": 5e-4}], overlap_comm=world > 1)
+        sc = torch.optim.lr_scheduler.LambdaLR(op, lr_lambda=lambda e: cosine_decay_linear_warmup(e, 10 * total_steps, 1.5 * total_steps))
+        return pr, op, sc
+
+    probe, opt, sched = make_probe()
     loss_fn = DepthLoss()
 
     # synthetic NYU-shaped batches, generated per (rank, step), resident in HBM before timing
@@ -283,6 +300,8 @@ def main():
     pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else (d0 if (d0 == 1 or os.environ.get("MVP_INFLIGHT") is not None) else None),
                            group=args.group)
     pipe.resolve_group(batches[0][0])
+    if args.pmc_child:
+        args.warmup, args.steps = pipe.group, 2 * pipe.group
     if args.tiles == "alone" and pipe.chains >= SHARED_TILES_FROM:
         raise SystemExit("--tiles alone contradicts --inflight >= 3 (the pipeline selects the shared-chip tiles)")
     # the tile policy of the timed run's backbone GEMMs; a serial chain (--inflight 1) can be forced to it for profiling
@@ -291,16 +310,17 @@ def main():
 
     from mvp.pipeline import pipelined_features
 
-    def run_steps(i0, n, out=None, pipe=pipe):
+    def run_steps(i0, n, out=None, pipe=pipe, objs=None):
         """Steps i0 .. i0+n-1, every one the full train_depth.py:99-143 body.  The frozen forwards of upcoming batches (stacked ``group``
         at a time) are in flight on side streams while the probe steps run in order on this stream; the pipeline starts empty and ends
         empty, so all the work of these n steps (the forwards of n batches, n probe forward/backward/AdamW) lies between the caller's two
         barriers."""
         seq = [batches[i % n_distinct] for i in range(i0, i0 + n)]
+        pr_, op_, sc_ = objs if objs is not None else (probe, opt, sched)
         ctx = shared_tiles(True) if (pipe.depth == 1 and force_shared) else contextlib.nullcontext()  # (a pipelined forward selects its policy itself)
         with ctx:
             for (images, target), feats in pipelined_features(model, seq, pipe=pipe):
-                loss = train_depth_step(model, probe, opt, sched, loss_fn, None, target, feats=feats)
+                loss = train_depth_step(model, pr_, op_, sc_, loss_fn, None, target, feats=feats)
                 if out is not None:
                     out.append(loss)
 
@@ -309,6 +329,20 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    # ---------------- in-run check (VERDICT r2 #2c): from identical probe / optimizer states, the pipelined loop (grouped forwards, graph
+    # replay) and the one-batch-at-a-time serial loop produce the same per-step losses, bit for bit.  (Also sets the pipeline's graphs up.)
+    pipeline_check = None
+    if pipe.depth > 1 and not args.pmc_child and world == 1:
+        nchk = pipe.group + min(2, pipe.group)  # one full group + a ragged one
+        la, lb = [], []
+        run_steps(0, nchk, la, pipe, make_probe())
+        torch.cuda.synchronize()
+        run_steps(0, nchk, lb, FeaturePipeline(model, 1), make_probe())
+        torch.cuda.synchronize()
+        same = bool(torch.equal(torch.stack(la), torch.stack(lb)))
+        pipeline_check = {"steps": nchk, "losses_bit_identical_to_serial_loop": same}
+        assert same, "the pipelined loop's losses differ from the serial loop's"
 
     from mvp.pipeline import freeze_gc
 
@@ -329,10 +363,11 @@ def main():
     images_per_s = world * B * args.steps / dt
 
     # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
-    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": "shared-chip (128x128)" if tiles_shared else "alone",
+    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": ("large-M 256x256 ping-pong kernel (gemm_pp.hip)" if pipe.group > 1 else "shared-chip (128x128)" if tiles_shared else "alone"),
                      "what": "frozen forwards of upcoming batches (stacked `group` at a time into one chain of launches: same bits per batch) run on side "
                              "HIP streams under the probe steps of the current batches; every step still runs its own full forward + probe "
                              "forward/backward/AdamW inside the timed region, and the pipeline is empty at both of its barriers"}
+    pipeline_info["check"] = pipeline_check
     if pipe.depth > 1 and not args.no_serial_leg:
         serial_pipe = FeaturePipeline(model, 1)
         barrier()
@@ -401,61 +436,89 @@ def main():
 
     gh, gw = -(-H // 16), -(-W // 16)
     N = 1 + gh * gw
-    f_img = flops_per_image(N)
+    f_img = flops_per_image(N, probe=args.probe)
 
-    # ---------------- roofline leg: per-launch HIP-event timing of the dominant kernel (GEMM)
+    # ---------------- roofline leg: per-launch HIP-event timing of every traced kernel, in the TIMED regime (the same pipeline shape,
+    # forwards on their side stream, probe steps beside them; eager launches so that each launch can be bracketed by events recorded on
+    # the stream it is launched on), then the forward's kernels once more with nothing beside them ("kernel_alone")
     roofline = None
     if not args.no_roofline:
         # every rank runs these extra steps (the optimiser step holds the gradient all-reduce); rank 0 reports
+        i_rl = args.warmup + args.steps
+        if pipe.depth > 1:
+            eager = FeaturePipeline(model, pipe.depth, graphs=False, group=pipe.group, streams=pipe.chains)
+            nrl = 2 * pipe.group
+        else:
+            eager, nrl = FeaturePipeline(model, 1), 3
+        run_steps(i_rl, nrl, None, eager)  # (allocates the eager pipeline's slot buffers)
+        barrier()
         trace = []
         ops.set_trace(trace)
-        nrep = 3
-        with shared_tiles(tiles_shared):  # the timed run's kernel instantiations, one at a time on one stream
-            for i in range(nrep):
-                step(args.warmup + args.steps + i)
+        with shared_tiles(tiles_shared) if pipe.depth == 1 else contextlib.nullcontext():
+            run_steps(i_rl, nrl, None, eager)
+        barrier()
+        alone = []
+        ops.set_trace(alone)
+        nalone = 0
+        if pipe.depth > 1:  # forwards only, one after the other: every kernel alone on the chip
+            for _ in range(2):
+                eager.submit_group([batches[i % n_distinct][0] for i in range(pipe.group)])
+                for _ in range(pipe.group):
+                    eager.next()
+                nalone += pipe.group
+            eager.drain()
         barrier()
         ops.set_trace(None)
     if not args.no_roofline and rank == 0:
-        groups, hbm = {}, {}
-        for kind, tile, prec, flops, e0, e1 in trace:
-            key = (kind, tile)
-            gsum = (hbm if kind == "hbm" else groups).setdefault(key, [0.0, 0.0, 0])
-            gsum[0] += flops
-            gsum[1] += e0.elapsed_time(e1) * 1e-3
-            gsum[2] += 1
+        def aggregate(tr):
+            groups, hbm = {}, {}
+            for kind, tile, prec, flops, e0, e1 in tr:
+                gsum = (hbm if kind == "hbm" else groups).setdefault((kind, tile), [0.0, 0.0, 0])
+                gsum[0] += flops
+                gsum[1] += e0.elapsed_time(e1) * 1e-3
+                gsum[2] += 1
+            return groups, hbm
+
+        groups, hbm = aggregate(trace)
+        groups_alone, _ = aggregate(alone)
         # dominant = the kernel instantiation with the largest total time
         dom = max(groups.items(), key=lambda kv: kv[1][1])
         (kind, tile), (fl, sec, cnt) = dom
         achieved = fl / sec / 1e12
-        name = ("gemm_pp_kernel<" + tile[3:] + ">" if tile.startswith("pp ") else f"gemm_kernel<{tile}>") if kind == "gemm" else "attention_kernel"
+        name = ("gemm_pp_kernel<" if tile.startswith("pp ") else "gemm_kernel<") if kind == "gemm" else "attention_kernel"
+        full_name = (("gemm_pp_kernel<" + tile[3:] + ">") if tile.startswith("pp ") else f"gemm_kernel<{tile}>") if kind == "gemm" else "attention_kernel"
         default_wl = (B, H, W, args.precision, args.probe) == (16, 224, 224, "bf16x3", "linear")
         traffic, traffic_src, busy = None, None, None
         if pmc_live:
-            hit = [v for k, v in pmc_live.items() if k.startswith(name.rstrip(">"))]
+            hit = [v for k, v in pmc_live.items() if k.startswith(name if tile.startswith("pp ") else full_name.rstrip(">"))]
             if hit:
-                traffic, busy, traffic_src = hit[0]["hbm_bytes"], hit[0]["mfma_busy"] or None, "live: rocprofv3 --pmc child passes of this invocation"
+                best = max(hit, key=lambda v: v["mfma_busy"] or 0.0)  # (the instantiation that did the work: layout variants share the prefix)
+                traffic, busy, traffic_src = best["hbm_bytes"], best["mfma_busy"] or None, "live: rocprofv3 --pmc child passes of this invocation"
         if traffic is None and default_wl:
-            traffic, traffic_src = pmc_traffic(name)
-            busy = pmc_mfma_busy(name)
+            traffic, traffic_src = pmc_traffic(name if tile.startswith("pp ") else full_name)
+            busy = pmc_mfma_busy(name if tile.startswith("pp ") else full_name)
             traffic_src = f"committed pass {traffic_src}"
-        clk = 2.1e9  # clock the chip holds under this load (in-kernel s_memtime / s_memrealtime)
+        ka = groups_alone.get((kind, tile))
+        sec_alone = (ka[1] / ka[2]) if ka else None
+        clk = 1.6e9 if tile.startswith("pp ") else 2.1e9  # clock the chip holds under this load (in-kernel s_memtime stamps vs wall time)
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
             "traffic": traffic, "traffic_unit": f"bytes/launch (memory-side, rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE; {traffic_src})",
             "mfma_busy": None if busy is None else {"SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy,
-                                                    "frac_of_simd_cycles": round(busy / (1024 * (sec / cnt) * clk), 3),
-                                                    "note": "PMC pass (see traffic_unit); 1024 SIMDs x live launch duration x 2.1 GHz"},
-            "hbm_kernels": {k[1]: {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2), "alg_mbytes_per_launch": round(v[0] / v[2] / 1e6, 2),
+                                                    "frac_of_simd_cycles": round(busy / (1024 * (sec_alone or sec / cnt) * clk), 3),
+                                                    "note": f"PMC pass (see traffic_unit); 1024 SIMDs x launch duration alone on the chip x {clk / 1e9:.1f} GHz (the clock the chip holds under this kernel)"},
+            "hbm_kernels": {k[1]: {"launches_per_step": round(v[2] / nrl, 2), "avg_us": round(v[1] / v[2] * 1e6, 2), "alg_mbytes_per_launch": round(v[0] / v[2] / 1e6, 2),
                                    "achieved_gbps": round(v[0] / v[1] / 1e9, 1), "frac_of_8TBps": round(v[0] / v[1] / 8e12, 3)} for k, v in hbm.items()},
-            "kernel": name, "launches_per_step": cnt // nrep, "avg_launch_us": round(sec / cnt * 1e6, 2),
+            "kernel": full_name, "launches_per_step": round(cnt / nrl, 2), "avg_launch_us": round(sec / cnt * 1e6, 2),
             "alg_gflop_per_launch": round(fl / cnt / 1e9, 3),
-            "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop); HIP events on the launch stream, taken in 3 extra "
-                    "steps that launch the timed run's kernel instantiations as ONE serial chain, so a launch duration is the kernel alone on the chip — "
-                    "what rocprofv3 reports for this command too (kernel tracing serialises dispatches across streams)",
+            "regime": "timed: HIP events around every launch (on the stream it is launched on) while the pipeline runs as in the timed region — "
+                      f"{pipe.group} batches per frozen forward on {pipe.chains} side stream(s), the probe steps of the previous batches beside it; eager launches instead of graph replay",
+            "note": "algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop: x3 = share of the bf16 MFMA pipe)",
+            "kernel_alone": None if not ka else {"avg_launch_us": round(ka[1] / ka[2] * 1e6, 2), "alg_tflops": round(ka[0] / ka[1] / 1e12, 2), "frac": round(ka[0] / ka[1] / 1e12 / 2500.0, 4),
+                                                 "note": "the same launches with nothing beside them (forwards only, one stream): what rocprofv3 --kernel-trace reports too"},
             "chip_level": {"alg_tflops": round(images_per_s / world * f_img / 1e12, 2), "frac": round(images_per_s / world * f_img / 1e12 / 2500.0, 4),
-                           "note": "whole-step algorithmic flops / measured step time of the timed run; with several forwards in flight the chains overlap, "
-                                   "so launches_per_step x avg_launch_us summed over all_kernels exceeds ms_per_step"},
-            "all_kernels": {f"{k[0]}:{k[1]}": {"launches_per_step": v[2] // nrep, "avg_us": round(v[1] / v[2] * 1e6, 2),
+                           "note": "whole-step algorithmic flops / measured step time of the timed run"},
+            "all_kernels": {f"{k[0]}:{k[1]}": {"launches_per_step": round(v[2] / nrl, 2), "avg_us": round(v[1] / v[2] * 1e6, 2),
                                                 "alg_tflops": round(v[0] / v[1] / 1e12, 2)} for k, v in groups.items()},
             "whole_step_alg_tflops": round(images_per_s / world * f_img / 1e12, 2),
         }

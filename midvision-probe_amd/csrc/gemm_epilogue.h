@@ -8,14 +8,23 @@ namespace {
 
 // Branch-free erf GELU: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one
 // v_rcp.  (ocml erff measured ~17 us of VALU on the fc1 epilogue.)
+// Every multiply-add is spelled out and contraction is off: the function is inlined into several epilogues (gemm_epilogue,
+// gemm_epilogue_wide) whose surrounding code would otherwise let the compiler fuse differently per call site — and a batch must get
+// the same bits whichever GEMM kernel its forward happens to use (grouped forwards use the large-M kernel, single batches the tiles).
 __device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
   const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = __expf(-ax * ax);
-  const float erf_abs = 1.0f - poly * e;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 1.421413741f);
+  poly = __builtin_fmaf(t, poly, -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  poly = t * poly;
+  const float e = __expf(-(ax * ax));
+  const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);
   const float erfv = copysignf(erf_abs, x);
-  return 0.5f * x * (1.0f + erfv);
+  const float hx = 0.5f * x;
+  return __builtin_fmaf(hx, erfv, hx);
 }
 
 // Logical tile index -> (tm, tn), XCD-region-major.  xcd_remap() hands each XCD one contiguous slice of the logical
@@ -203,6 +212,122 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
       }
     }
   }
+}
+
+// Wide epilogue of the large-M kernel (gemm_pp.hip) for the combinations the ViT blocks use — compiled per combination, no runtime
+// feature branches.  Same arithmetic as gemm_epilogue() (bias, erf-GELU, fp32 residual, fp32 and / or bf16-pair output, row remap),
+// hence the same bits, but shaped for the memory system, which is what bounds it: when every CU of a round reaches its epilogue at
+// once, 58-232 MB leave the chip in one burst, and that burst ran at 2.8-3.5 TB/s against the 6.9 TB/s a plain fill reaches
+// (in-kernel stamps: 27 % of the qkv GEMM, 20 % of fc2).  What it changes:
+//   * a lane owns 8 consecutive columns (two b128 reads of the per-wave LDS scratch): every store is 16 bytes per lane — the pair
+//     halves left as 8-byte stores before, which run at 0.5-0.7x the 16-byte rate on gfx950;
+//   * the residual rows of the NEXT 32-row chunk are loaded before the stores of the current one are issued: vmcnt retires in issue
+//     order, so a residual load issued behind a store waits for that store's whole round trip (the generic loop did that once per
+//     row group: a dependent load -> store -> load chain).
+// N % 8 == 0 and 16-byte-aligned rows are required (the caller checks and falls back to gemm_epilogue()).
+template <int NT, int MT, int WN, int ACT, bool RES, bool F32OUT, bool PAIR>
+__device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
+                                                   const int m0, const int n0, const int wm0, const int wn0) {
+  static_assert(WN == 64 && NT == 4 && (MT % 2) == 0, "wave tile 32k x 64");
+  constexpr int EPW = WN + 4;                 // padded scratch row, floats
+  constexpr int EP_BYTES = 32 * EPW * 4;      // per wave
+  constexpr int NIT = 4;                      // 8 rows per wave-instruction, 32 rows per chunk
+  const int frow = lane & 15, fq = lane >> 4;
+  float* ep = (float*)(smem + wave * EP_BYTES);
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+  const int ncol = n0 + wn0 + ec;
+  const bool col_ok = ncol < p.N;  // (N % 8 == 0: the 8 columns are all in or all out)
+  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias && col_ok) {
+    const float4 b0 = *(const float4*)(p.bias + ncol), b1 = *(const float4*)(p.bias + ncol + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;
+  auto out_row = [&](int m) {
+    if (p.row_group <= 0) return m;
+    const int gidx = m / p.row_group;
+    return gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
+  };
+  float4 rpre[NIT][2];
+  auto load_res = [&](int h) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wm0 + h * 32 + it * 8 + er;
+      rpre[it][0] = rpre[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M && col_ok) {
+        const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : out_row(m);
+        const float* rp = p.residual + (size_t)rrow * p.ldr + ncol;
+        rpre[it][0] = *(const float4*)rp;
+        rpre[it][1] = *(const float4*)(rp + 4);
+      }
+    }
+  };
+  if (RES) load_res(0);
+#pragma unroll
+  for (int h = 0; h < MT / 2; ++h) {
+    // accumulators -> LDS (lane: row frow of the m-fragment, columns i*16 + 4*fq ..)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) *(f32x4_t*)(ep + (jj * 16 + frow) * EPW + i * 16 + fq * 4) = acc[i][h * 2 + jj];
+    float v[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int lr = it * 8 + er;
+      const f32x4_t a = *(const f32x4_t*)(ep + lr * EPW + ec), b = *(const f32x4_t*)(ep + lr * EPW + ec + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + bias8[e]; v[it][4 + e] = b[e] + bias8[4 + e]; }
+      if (ACT == MVP_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
+      }
+      if (RES) {
+        v[it][0] += rpre[it][0].x; v[it][1] += rpre[it][0].y; v[it][2] += rpre[it][0].z; v[it][3] += rpre[it][0].w;
+        v[it][4] += rpre[it][1].x; v[it][5] += rpre[it][1].y; v[it][6] += rpre[it][1].z; v[it][7] += rpre[it][1].w;
+      }
+    }
+    if (RES && h + 1 < MT / 2) load_res(h + 1);  // issued BEFORE this chunk's stores: its data never waits behind them
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + wm0 + h * 32 + it * 8 + er;
+      if (m >= p.M || !col_ok) continue;
+      const int orow = out_row(m);
+      if (F32OUT) {
+        float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
+        *(float4*)op = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+        *(float4*)(op + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+      }
+      if (PAIR) {
+        uint32_t hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2_bf16(v[it][2 * e], v[it][2 * e + 1], hh[e], ll[e]);
+        if (oilv) {
+          mvp_bf16* o = p.out_hi + (size_t)orow * p.ldob + ilv32_col(ncol);
+          *(u32x4_t*)o = u32x4_t{hh[0], hh[1], hh[2], hh[3]};
+          *(u32x4_t*)(o + 32) = u32x4_t{ll[0], ll[1], ll[2], ll[3]};
+        } else {
+          const size_t o = (size_t)orow * p.ldob + ncol;
+          *(u32x4_t*)(p.out_hi + o) = u32x4_t{hh[0], hh[1], hh[2], hh[3]};
+          if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{ll[0], ll[1], ll[2], ll[3]};
+        }
+      }
+    }
+  }
+}
+
+// Which wide-epilogue instantiation serves these arguments (0 = none: the generic epilogue).
+__device__ __forceinline__ int gemm_epilogue_wide_variant(const mvp_gemm_args& p) {
+  if (p.relu_mask || p.out_mask || p.residual2 || p.act_after_res || p.residual_hi) return 0;
+  if ((p.N & 7) || (p.act != MVP_ACT_NONE && p.act != MVP_ACT_GELU)) return 0;
+  if (p.residual && ((p.ldr & 3) || ((size_t)p.residual & 15))) return 0;
+  if (p.out_f32 && ((p.ldo & 3) || ((size_t)p.out_f32 & 15))) return 0;
+  if (p.out_hi && ((p.ldob & 7) || ((size_t)p.out_hi & 15) || (p.out_lo && ((size_t)p.out_lo & 15)))) return 0;
+  if (p.bias && ((size_t)p.bias & 15)) return 0;
+  const bool pair = p.out_hi != nullptr, f32 = p.out_f32 != nullptr, res = p.residual != nullptr, gelu = p.act == MVP_ACT_GELU;
+  if (pair && !f32 && !res) return gelu ? 2 : 1;   // qkv / fc1
+  if (f32 && !pair && res && !gelu) return 3;      // proj / fc2 / patch embedding
+  if (f32 && !pair && !res) return gelu ? 5 : 4;
+  return 0;
 }
 
 }  // namespace

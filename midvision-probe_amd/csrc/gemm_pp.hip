@@ -68,6 +68,9 @@ template <bool ILVA, bool ILVW, bool EXT>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MT = 8, NT = 4;
+#if MVP_PP_STAMP
+  const uint64_t t_k0 = __builtin_amdgcn_s_memtime();
+#endif
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform (SGPR): LDS-DMA destinations, resource choice
   const int wr = wave >> 2, wc = wave & 3;
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #if MVP_PP_STAMP
   uint64_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint64_t s_e = __builtin_amdgcn_s_memtime(), s_x = 0;
+  const uint64_t t_l0 = s_e;
 #endif
   auto kstep = [&](int t, auto PAR) {
     constexpr int par = decltype(PAR)::value;
@@ -290,15 +294,33 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   if (t < nk) kstep(t, ic<0>{});
   if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last interval
 #if MVP_PP_STAMP
-  if (p.splitk_ws && wc == 0 && lane == 0) {
-    uint64_t* dbg = (uint64_t*)p.splitk_ws + ((size_t)blockIdx.x * 2 + wr) * 10;
-    for (int c = 0; c < 10; ++c) dbg[c] = tacc[c];
-  }
+  const uint64_t t_l1 = __builtin_amdgcn_s_memtime();
 #endif
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();  // every wave is done with the staging buffers -> the epilogue reuses them
 
-  gemm_epilogue<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0);
+#ifndef MVP_PP_WIDE_EPILOGUE
+#define MVP_PP_WIDE_EPILOGUE 1  // 0 (diagnostic builds): always the generic epilogue
+#endif
+  const int wide = (!EXT && MVP_PP_WIDE_EPILOGUE) ? gemm_epilogue_wide_variant(p) : 0;  // wave-uniform: kernel arguments only
+  switch (wide) {
+    case 1: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, false, true>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
+    case 2: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, false, true>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
+    case 3: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, true, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
+    case 4: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
+    case 5: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
+    default: gemm_epilogue<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0);
+  }
+#if MVP_PP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left
+  const uint64_t t_e1 = __builtin_amdgcn_s_memtime();
+  if (p.splitk_ws && wc == 0 && lane == 0) {
+    uint64_t* dbg = (uint64_t*)p.splitk_ws + ((size_t)blockIdx.x * 2 + wr) * 16;
+    for (int c = 0; c < 10; ++c) dbg[c] = tacc[c];
+    dbg[10] = t_l0 - t_k0; dbg[11] = t_l1 - t_l0; dbg[12] = t_e1 - t_l1; dbg[13] = t_k0; dbg[14] = t_e1;
+    dbg[15] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <bool ILVA, bool ILVW>

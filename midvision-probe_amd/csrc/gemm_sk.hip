@@ -36,12 +36,20 @@ constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 64, SK_NW = 8;
 constexpr int SK_CTR_BYTES = 65536;
 constexpr int SK_PART_BYTES = SK_BM * SK_BN * 4;  // one fp32 partial tile
 
-__device__ __forceinline__ float sk_gelu_erf(float x) {  // Abramowitz-Stegun 7.1.26 (same as gemm.hip)
+__device__ __forceinline__ float sk_gelu_erf(float x) {  // Abramowitz-Stegun 7.1.26: the same operations, in the same order, as gemm_epilogue.h's gelu_erf
+#pragma clang fp contract(off)
   const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = __expf(-ax * ax);
-  return 0.5f * x * (1.0f + copysignf(1.0f - poly * e, x));
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 1.421413741f);
+  poly = __builtin_fmaf(t, poly, -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  poly = t * poly;
+  const float e = __expf(-(ax * ax));
+  const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);
+  const float erfv = copysignf(erf_abs, x);
+  const float hx = 0.5f * x;
+  return __builtin_fmaf(hx, erfv, hx);
 }
 
 // logical tile index -> (tm, tn): the 8 XCD slices of the (contiguous) iteration space map to XR x XC rectangles of the

@@ -214,6 +214,7 @@ class FeaturePipeline:
             self.group = 1
         # (stream priorities do not help: the device offers only (0, -1), and high-priority side streams measured the same)
         # ``depth`` forwards are submitted ahead (one buffer slot each); they run on ``streams`` side streams = kernel chains side by side
+        self._streams_given = streams is not None or os.environ.get("MVP_PIPELINE_STREAMS") is not None
         if streams is None:
             streams = int(os.environ.get("MVP_PIPELINE_STREAMS", str(MAX_STREAMS)))
         self._streams_arg = int(streams)
@@ -253,7 +254,11 @@ class FeaturePipeline:
             if self.group > 1 and self._depth_arg is None and os.environ.get("MVP_INFLIGHT") is None:
                 # grouped forwards: two slots (one group being consumed, the next one's forward running); see default_depth
                 self.depth = 2
-                self.chains = max(1, min(self.depth, self._streams_arg))
+            if self.group > 1:
+                # ... on ONE side stream unless asked otherwise: a grouped forward's GEMMs fill the chip by themselves (one 256x256 tile per
+                # CU), a second forward chain beside them adds nothing (measured, B = 16, 6 batches per forward, img/s at 20 / 60 steps:
+                # one stream 8357 / 8706, two 8326 / 8714), and one chain keeps every per-kernel measurement in the regime of the timed run
+                self.chains = max(1, min(self.depth, self._streams_arg if self._streams_given else 1))
                 self.streams = self.streams[:self.chains]
         return self.group
 

@@ -64,7 +64,16 @@ def main(argv):
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(
         e, n_ep * len(loader), cfg["optimizer"]["warmup_epochs"] * len(loader)))
     hist = []
-    if not cfg.get("is_eval", False):
+    is_eval = bool(cfg.get("is_eval", False))
+    loaded_ckpt = None
+    if is_eval:
+        # train_depth.py:526-535,570: an evaluation run scores the probe of cfg.ckpt_path (probe only: the reference's model line is
+        # commented out); without a checkpoint it would score a randomly initialised probe under the real experiment's CSV columns
+        loaded_ckpt = str(cfg.get("ckpt_path", "") or "").replace("\\$", "$")
+        if not loaded_ckpt:
+            raise SystemExit("is_eval=True needs ckpt_path=<.../ckpt.pth> (refusing to validate a randomly initialised probe)")
+        checkpoint.load_checkpoint(loaded_ckpt, model, probe, load_model=False)
+    else:
         hist = train(model, probe, loader, opt, sched, n_ep, detach_model=True, loss_fn=DepthLoss(), rank=rank, world_size=world)
     opt.finish_pending()
     if rank == 0:
@@ -73,14 +82,14 @@ def main(argv):
         vcfg = dict(ds, num_batches=2, batch_size=cfg["batch_size"])
         timestamp, exp_name, exp_info = results.experiment_info(cfg, model, probe, ds["name"], ds["name"])
         out = os.path.join(cfg["output_dir"], "depth_exps", exp_name.replace("$", ""))
-        ckpt = os.path.join(out, "ckpt.pth")
+        ckpt = loaded_ckpt if is_eval else os.path.join(out, "ckpt.pth")  # the CSV's ckpt_path column names what was scored
         sa_loss, sa_g, sa_l = validate(model, probe, build_loader(vcfg, "valid", cfg["batch_size"], with_snorm=False), DepthLoss(), is_navi=is_navi)
         si_loss, si_g, si_l = validate(model, probe, build_loader(vcfg, "valid", cfg["batch_size"], with_snorm=False), DepthLoss(),
                                        scale_invariant=True, is_navi=is_navi)
         print(f"train loss/epoch {hist} | SA valid loss {sa_loss:.4f} d1 {sa_g['d1']:.4f} rmse {sa_g['rmse']:.4f} | SI loss {si_loss:.4f} rmse {si_g['rmse']:.4f}")
         titles, row = results.depth_result_row(timestamp, exp_info, sa_g, si_g, sa_l, si_l, ckpt, ds["name"])
         print("results ->", results.append_result_csv(results.result_csv_path(cfg["output_dir"], "depth", ds["name"], bool(cfg["backbone"].get("add_norm"))), titles, row))
-        if not cfg.get("is_eval", False):
+        if not is_eval:
             print("saved", checkpoint.save_checkpoint(ckpt, cfg, model, probe))
     if world > 1:
         torch.distributed.destroy_process_group()

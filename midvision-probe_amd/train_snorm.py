@@ -42,7 +42,13 @@ def main(argv):
     n_ep = cfg["optimizer"]["n_epochs"]
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: cosine_decay_linear_warmup(e, n_ep * nb, cfg["optimizer"]["warmup_epochs"] * nb))
     freeze_gc()  # no full-heap collector pause inside the loop
-    for ep in range(n_ep):
+    is_eval = bool(cfg.get("is_eval", False))
+    if is_eval:  # train_snorm.py:541-542: an evaluation run loads model AND probe of cfg.ckpt_path
+        ck = str(cfg.get("ckpt_path", "") or "").replace("\\$", "$")
+        if not ck:
+            raise SystemExit("is_eval=True needs ckpt_path=<.../ckpt.pth> (refusing to validate a randomly initialised probe)")
+        checkpoint.load_checkpoint(ck, model, probe, load_model=True)
+    for ep in range(0 if is_eval else n_ep):
         tot = 0.0
         if world > 1:
             loader.sampler.set_epoch(ep)
@@ -61,7 +67,8 @@ def main(argv):
         gm, _, _ = evaluate_surface_norm(pred, b["snorm"].to(dev), None, image_average=True, is_navi=True)
         print("valid " + " ".join(f"{k} {float(v):.4f}" for k, v in gm.items()))
         out = os.path.join(cfg["output_dir"], "snorm_exps", f"{model.checkpoint_name}_{probe.name}".replace("$", ""))
-        print("saved", checkpoint.save_checkpoint(os.path.join(out, "ckpt.pth"), cfg, model, probe))
+        if not is_eval:
+            print("saved", checkpoint.save_checkpoint(os.path.join(out, "ckpt.pth"), cfg, model, probe))
     if world > 1:
         torch.distributed.destroy_process_group()
 

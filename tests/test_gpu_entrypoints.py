@@ -43,6 +43,20 @@ def test_train_depth_entrypoint_writes_csv_and_checkpoint(tmp_path):
     blob = torch.load(ck, map_location="cpu", weights_only=True)
     assert set(blob) == {"cfg", "model", "probe"} and set(blob["probe"]) == {"head.conv.weight", "head.conv.bias"}
     assert float(rows[1][titles.index("rmse SA")]) > 0
+    # is_eval=True ckpt_path=...: the saved probe is loaded and scored (train_depth.py:526-535,570) -> the same metrics, the loaded
+    # path in the ckpt_path column, nothing saved; without a ckpt_path the run refuses to score a randomly initialised probe
+    args = ["backbone=dino_b16", "+backbone.return_multilayer=True", "probe=depth_linear", f"output_dir={tmp_path}/result", "is_eval=True"] + COMMON
+    out = _run("train_depth.py", args + [f"ckpt_path={ck}"], str(tmp_path))
+    assert "results ->" in out and "saved" not in out
+    rows2 = list(csv.reader(open(files[0])))
+    assert len(rows2) == 3 and rows2[2][-1] == ck
+    # (not bit-equal: depth evaluation loads the PROBE only — the reference's model line is commented out, train_depth.py:533-535 — so
+    # the backbone's tap-BN running statistics are the freshly initialised ones, not those the training run had accumulated)
+    for col in ("rmse SA", "d1 SA", "rmse SI"):
+        a, b = float(rows2[2][titles.index(col)]), float(rows2[1][titles.index(col)])
+        assert abs(a - b) <= 2e-2 * abs(b) + 1e-6, (col, a, b)
+    p = subprocess.run([sys.executable, os.path.join(PKG, "train_depth.py")] + args, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode != 0 and b"ckpt_path" in p.stdout
 
 
 @pytest.mark.timeout(900)

@@ -1,0 +1,12 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python bench.py --steps 20 --warmup 5 > gpurun_out/r3_bench_a.json 2> gpurun_out/r3_bench_a.err; echo "rc=$?"
+tail -3 gpurun_out/r3_bench_a.err
+python3 - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/r3_bench_a.json") if l.startswith("{")][-1])
+r = d.pop("roofline"); 
+print({k: d[k] for k in ("value", "ms_per_step", "pipeline", "sustained", "cpu_baseline")})
+print({k: r[k] for k in r if k not in ("all_kernels", "hbm_kernels", "note", "regime", "traffic_unit")})
+print(r["all_kernels"]); print(r["hbm_kernels"])
+PY

@@ -145,19 +145,23 @@ def main():
                     out = ops.empty_pair((M, n), 3, dev) if d["pair_out"] else None
                     o32 = torch.empty(M, n, device=dev) if d["f32_out"] else None
                     tiles = ((M + 255) // 256) * ((n + 255) // 256)
-                    dbg = torch.zeros(tiles * 2 * 10, dtype=torch.int64, device=dev)
+                    dbg = torch.zeros(tiles * 2 * 16, dtype=torch.int64, device=dev)
                     g = args_for(d, 3 if ilv else 0, out, o32)
                     g.splitk_ws, g.splitk_ws_bytes = dbg.data_ptr(), dbg.numel() * 8
                     for _ in range(3):
                         rc = lst.mvp_gemm_pp(C.byref(g), st)
                     torch.cuda.synchronize()
                     assert rc == 0
-                    t = dbg.view(tiles, 2, 2, 5).double() / (k // 32)  # cycles per phase, [tile, group, phase type, segment]
+                    raw = dbg.view(tiles, 2, 16).double()
+                    t = raw[:, :, :10].reshape(tiles, 2, 2, 5) / (k // 32)  # cycles per phase, [tile, group, phase type, segment]
                     mean = t.mean(dim=0)
                     print(f"stamp B={B} {name} ilv={ilv} tiles={tiles}: cycles per phase (mean over workgroups; group 0 | group 1)")
                     for ph in range(2):
                         print(f"   P{ph + 1}: " + "  ".join(f"{names[c]}={mean[0, ph, c]:.0f}|{mean[1, ph, c]:.0f}" for c in range(5))
                               + f"   total={mean[0, ph].sum():.0f}|{mean[1, ph].sum():.0f}", flush=True)
+                    pro, loop, epi = raw[:, :, 10].mean().item(), raw[:, :, 11].mean().item(), raw[:, :, 12].mean().item()
+                    span = (raw[:, :, 14].max() - raw[:, :, 13].min()).item()  # first workgroup start -> last workgroup end (s_memtime is one clock per XCD: indicative)
+                    print(f"   per workgroup: prologue {pro:.0f} cycles, main loop {loop:.0f}, epilogue + store drain {epi:.0f}; kernel span ~{span:.0f} cycles", flush=True)
         return 0
 
     # ------------------------------------------------------------------ timing
@@ -167,6 +171,8 @@ def main():
     if "--ablate" in sys.argv:
         for n, nm in ((1, "no_mfma"), (2, "no_dma"), (3, "no_read")):
             extra[nm] = build_ablate(n)
+    if "--epilogue-ab" in sys.argv:  # the generic epilogue (gemm_epilogue) instead of the wide one, same main loop
+        extra["generic_epilogue"] = build_ablate(0, "MVP_PP_WIDE_EPILOGUE", "wide")
     for B in Bs:
         M = B * 197
         for name, n, k, kw in (("qkv", 2304, 768, {}), ("proj", 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
