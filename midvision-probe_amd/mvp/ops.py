@@ -154,7 +154,12 @@ def streamk_auto(M: int, N: int, K: int, precision: int) -> bool:
 
 
 def _ws_key(device):
-    # launches on one stream are ordered, so they may share a workspace; launches on different streams (mvp/pipeline.py) may not
+    # launches on one stream are ordered, so they may share a workspace; launches on different streams (mvp/pipeline.py) may not.
+    # A pipelined forward is keyed by its SLOT, not by the stream it happens to be enqueued on: every slot's hipGraph is captured on
+    # one stream and replayed on whichever stream its turn falls on, so a stream-keyed workspace would be baked into several graphs
+    # that replay side by side
+    if pipeline.pipelined():
+        return (device, "slot", pipeline.current_slot())
     return (device, lib.stream_ptr())
 
 

@@ -30,17 +30,24 @@ def grad_destination(param: torch.Tensor):
     flat, off, n, shape, ref = ent
     if ref() is not param:  # id reuse after the parameter died
         return None
+    if param.grad is not None:
+        # a second backward() before step() (gradient accumulation): the slot already holds g1 and param.grad aliases it — writing g2
+        # there and letting autograd add "the returned gradient" to param.grad would yield 2 * g2.  A fresh tensor makes autograd
+        # accumulate g1 + g2 (FlatAdamW.zero_grad drops .grad, so the trainers' one-backward-per-step path still writes in place).
+        return None
     return flat[off:off + n].view(shape)
 
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, process_group=None,
-                 overlap_comm: bool = False, broadcast_init: bool = True):
+                 overlap_comm: bool = False, broadcast_init: bool = True, force_comm: bool = False):
         """``overlap_comm``: start the flat-gradient all-reduce asynchronously in ``step()`` (on a copy of the gradient, so
         ``zero_grad`` may run at once) and apply AdamW in ``finish_pending()`` — the trainers call that right before the next
         probe forward, so the collective runs under the next step's frozen backbone forward (which does not read the probe
         weights).  The reference overlaps the same exchange with backward through DDP buckets (train_depth.py:620-622).
-        ``broadcast_init``: rank 0's parameters are broadcast at construction, as the DDP wrap does."""
+        ``broadcast_init``: rank 0's parameters are broadcast at construction, as the DDP wrap does.
+        ``force_comm`` (test hook, also MVP_FORCE_COMM=1): take the overlapped collective path at world size 1 too — a one-GPU box can
+        then run the real RCCL all-reduce, its stream hand-over (``work.wait()``) and the deferred AdamW (tests/test_gpu_dist.py)."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:
@@ -77,6 +84,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step = 0
         self.process_group = process_group
         self.overlap_comm = bool(overlap_comm)
+        import os
+
+        self.force_comm = bool(force_comm) or os.environ.get("MVP_FORCE_COMM") == "1"
         self._pending = None  # (work handle | None, world, lr, step) of a started-but-unapplied update
         self._comm_buf = None
         from .dist import world_size as _world
@@ -145,7 +155,7 @@ class FlatAdamW(torch.optim.Optimizer):
         from .dist import world_size as _world
 
         world = _world(self.process_group)
-        if self.overlap_comm and world > 1:
+        if self.overlap_comm and (world > 1 or (self.force_comm and torch.distributed.is_available() and torch.distributed.is_initialized())):
             import torch.distributed as dist
 
             if self._comm_buf is None:

@@ -226,16 +226,10 @@ class FeaturePipeline:
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
         self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
         if graphs is None:
-            env = os.environ.get("MVP_PIPELINE_GRAPHS")
-            if env is not None:
-                graphs = env != "0"
-            else:
-                # Capture with RCCL work in flight (its watchdog thread queries events) could not be exercised on the one-GPU test pool:
-                # multi-rank jobs launch eagerly unless asked otherwise.  At the per-GPU batch sizes where replay pays (B <= 8) set
-                # MVP_PIPELINE_GRAPHS=1; at B = 16 the run is device-bound either way.
-                import torch.distributed as dist
-
-                graphs = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+            # On by default, multi-rank jobs included: capture and replay beside RCCL's stream and watchdog thread were exercised on the
+            # one-GPU pool with a real RCCL all-reduce per step (tests/test_gpu_dist.py::test_rccl_world1_overlapped_allreduce_with_graph_replay:
+            # bit-identical trajectory); capture_error_mode="thread_local" keeps other threads' HIP calls out of the capture.
+            graphs = os.environ.get("MVP_PIPELINE_GRAPHS", "1") != "0"
         self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
         self._graphs = {}  # (slot, shape, dtype, training, engine id, group) -> dict(calls, graph, static_in, feats, deferred)
         self._stage = {}   # (slot, shape, dtype) -> stacked input buffer of eager grouped forwards

@@ -112,6 +112,9 @@ def train(model, probe, train_loader, optimizer, scheduler, n_epochs, detach_mod
             loss = train_depth_step(model, probe, optimizer, scheduler, loss_fn, None, target, detach_model, scale_invariant, feats=feats)
             train_loss += loss.item()  # the reference syncs every step too (train_depth.py:143)
         history.append(train_loss / max(len(train_loader), 1))
+    # FlatAdamW(overlap_comm=True): the last step's all-reduce + AdamW are still pending — a caller that validates or saves
+    # probe.state_dict() next must see the final weights (optimizer.state_dict() is not on that path)
+    _finish_pending(optimizer)
     return history
 
 

@@ -509,11 +509,78 @@ def golden_spair():
     print("spair", out["pred_max"][:4].tolist(), out["tie_max"][:3].tolist(), out["tie_min"][:3].tolist())
 
 
+def golden_mae():
+    """Pins the MAE path (evals/models/mae.py:33,91-104,203-237) to the third-party arithmetic it calls: HF transformers' ViTMAE encoder.
+
+    ``transformers.ViTMAEModel(ViTMAEConfig(...))`` is built from a config (no fetch) with seeded weights, and the reference wrapper's
+    glue is replayed around ITS modules: embed_forward without masking (patch embeddings + pos[1:], CLS + pos[0]: mae.py:91-104), the
+    encoder layers one by one collecting hidden_states (index 0 = the embedding output, index i = output of layer i-1, as
+    ``output_hidden_states=True`` returns them), taps hidden_states[multilayers] -> nn.BatchNorm1d (train mode) -> dense map
+    (mae.py:216-236).  Caveat, stated here because the fixture cannot: the image holds transformers 5.15 (layers.i.attention.q_proj
+    ...), the reference pins 4.29.2 (encoder.layer.i.attention.attention.query ...): same pre-LN block (LayerNorm eps 1e-12, separate
+    q / k / v linears with bias, exact-erf GELU), different attribute names; the weights are saved under the 4.29.2 names the wrapper's
+    checkpoint loader expects.  The model's own position embeddings (HF's 2-D sincos initialisation) are stored as well: they pin the
+    sincos table the wrapper rebuilds in resize_pos_embed (mae.py:74-89, utils.py:75-102)."""
+    import torch.nn as nn
+    from transformers import ViTMAEConfig, ViTMAEModel
+
+    torch.manual_seed(1234)
+    D, depth, heads, img = 128, 4, 2, 96
+    cfg = ViTMAEConfig(hidden_size=D, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=4 * D, image_size=img, patch_size=16, mask_ratio=0.0)
+    m = ViTMAEModel(cfg).eval()
+    m.embeddings.patch_embeddings.projection._is_hf_initialized = False  # (post_init has marked the module done: run the sincos initialisation again)
+    m.embeddings.initialize_weights()  # HF's own 2-D sincos table for the config's grid (what from_pretrained checkpoints carry)
+    with torch.no_grad():  # HF initialises linears with std 0.02 and zero biases: give every tensor some signal
+        for n, p_ in m.named_parameters():
+            if "position_embeddings" in n:
+                continue
+            if p_.dim() == 1:
+                p_.copy_(torch.randn_like(p_) * 0.05 + (1.0 if "layernorm" in n and n.endswith("weight") else 0.0))
+            elif "cls_token" in n:
+                p_.copy_(torch.randn_like(p_) * 0.02)
+    images = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(77))
+    multilayers = [depth // 4 - 1, depth // 2 - 1, depth // 4 * 3 - 1, depth - 1]
+    with torch.no_grad():
+        emb = m.embeddings.patch_embeddings(images) + m.embeddings.position_embeddings[:, 1:, :]
+        cls = (m.embeddings.cls_token + m.embeddings.position_embeddings[:, :1, :]).expand(emb.shape[0], -1, -1)
+        x = torch.cat((cls, emb), dim=1)
+        hidden = [x]
+        for layer in m.layers:
+            x = layer(x)
+            hidden.append(x)
+        gh = gw = img // 16
+        out = {"images": _np(images), "multilayers": np.asarray(multilayers), "heads": np.asarray(heads), "pos_embed_hf": _np(m.embeddings.position_embeddings)}
+        for j, li in enumerate(multilayers):
+            bn = nn.BatchNorm1d(D)  # fresh, train mode, identity affine: as the wrapper's batchnorms at their first step
+            xi = hidden[li]
+            y = bn(xi.permute(0, 2, 1)).permute(0, 2, 1)
+            out[f"tokens_{j}"] = _np(xi)
+            out[f"dense_{j}"] = _np(y[:, 1:].reshape(2, gh, gw, D).permute(0, 3, 1, 2).contiguous())
+    sd = m.state_dict()
+    ren = {"embeddings.cls_token": "embeddings.cls_token", "embeddings.position_embeddings": "embeddings.position_embeddings",
+           "embeddings.patch_embeddings.projection.weight": "embeddings.patch_embeddings.projection.weight",
+           "embeddings.patch_embeddings.projection.bias": "embeddings.patch_embeddings.projection.bias",
+           "layernorm.weight": "layernorm.weight", "layernorm.bias": "layernorm.bias"}
+    sub = {"attention.q_proj": "attention.attention.query", "attention.k_proj": "attention.attention.key", "attention.v_proj": "attention.attention.value",
+           "attention.o_proj": "attention.output.dense", "layernorm_before": "layernorm_before", "layernorm_after": "layernorm_after",
+           "mlp.fc1": "intermediate.dense", "mlp.fc2": "output.dense"}
+    for k, v in sd.items():
+        if k in ren:
+            out["w:" + ren[k]] = _np(v)
+            continue
+        assert k.startswith("layers."), k
+        _, i, rest = k.split(".", 2)
+        mod, leaf = rest.rsplit(".", 1)
+        out[f"w:encoder.layer.{i}.{sub[mod]}.{leaf}"] = _np(v)
+    np.savez_compressed(os.path.join(OUT, "mae_tiny.npz"), **out)
+    print("mae_tiny", [float(np.abs(out[f"dense_{j}"]).mean()) for j in range(4)], "pos_embed |max|", float(np.abs(out["pos_embed_hf"]).max()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     vt, pr, ls, op = _load_reference()
-    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics", "metrics_seg", "spair", "probes_multiscale", "si_train"]
+    which = sys.argv[1:] or ["vit_tiny", "vit_tiny128", "vit_base", "probes", "losses", "optim", "step", "metrics", "metrics_seg", "spair", "probes_multiscale", "si_train", "mae"]
     if "vit_tiny" in which:
         golden_vit_tiny(vt)
     if "vit_tiny128" in which:
@@ -538,6 +605,8 @@ def main():
         golden_si_train(ls)
     if "spair" in which:
         golden_spair()
+    if "mae" in which:
+        golden_mae()
 
 
 if __name__ == "__main__":

@@ -91,3 +91,21 @@ def test_two_rank_product_step_matches_mean_gradient_emulation(tmp_path):
         np.testing.assert_array_equal(r0["losses"], ref_losses[0])
         np.testing.assert_array_equal(r1["losses"], ref_losses[1])
         assert not np.array_equal(r0["losses"], r1["losses"])  # the ranks really saw different shards
+
+
+def test_rccl_world1_overlapped_allreduce_with_graph_replay(tmp_path):
+    """The RCCL branch of FlatAdamW on the one GPU this pool has: init_process_group("nccl", world_size=1) and the
+    ``force_comm`` hook send every step's flat gradient through a real RCCL all_reduce(async_op=True) -> work.wait() -> AdamW, with the
+    pipeline's grouped forwards replaying captured hipGraphs beside RCCL's stream and watchdog thread.  The trajectory (losses, weights,
+    AdamW second moments) is bit-identical to the non-distributed one.  (Reference: DDP wrap of the probe, train_depth.py:620-622.)"""
+    out = tmp_path / "w1.npz"
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_world1.py"), str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    r = np.load(out)
+    assert str(r["backend"]) == "nccl"
+    assert np.isfinite(r["la"]).all()
+    np.testing.assert_array_equal(r["lb"], r["la"])
+    np.testing.assert_array_equal(r["pb"], r["pa"])
+    np.testing.assert_array_equal(r["vb"], r["va"])

@@ -482,3 +482,18 @@ def test_timed_configuration_b16_224_grouped_graphs_vs_serial_and_oracle():
         assert np.sqrt((d * d).sum() / (fr.numpy().astype(np.float64) ** 2).sum()) < 1e-3
     loss0, _ = tr.forward_loss(tr.features(host[0][0]), host[0][1].clone())
     assert abs(got[0][0] - loss0.item()) < 2e-3 * abs(loss0.item())
+
+
+def test_streamk_workspace_is_per_slot_under_graph_replay(monkeypatch):
+    """With MVP_STREAMK=1 every plain backbone GEMM takes the stream-K kernel, whose partial-tile workspace must not be shared by
+    forwards that replay side by side.  The workspace is keyed by pipeline slot (not by the stream a slot was captured on: every slot's
+    hipGraph is captured on one stream and replayed on rotating ones — ADVICE r2): pipelined + replayed == serial, bit for bit."""
+    from mvp import ops
+
+    monkeypatch.setattr(ops, "_STREAMK_MODE", "1")
+    monkeypatch.setattr(ops, "_STREAMK_WS", {})
+    ref = _run(1)
+    got = _run(4, graphs=True)
+    assert len({k for k in ops._STREAMK_WS if len(k) == 3 and k[1] == "slot"}) == 4  # one workspace per slot
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])

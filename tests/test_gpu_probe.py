@@ -301,3 +301,40 @@ def test_losses_degenerate_masks_match_reference_semantics(dev):
         assert torch.isnan(loss).item() == torch.isnan(ref).item()
         if not torch.isnan(ref):
             assert abs(loss.item() - ref.item()) < 1e-5 * max(abs(ref.item()), 1e-3)
+
+
+def test_flat_adamw_two_backwards_before_step_accumulate(dev):
+    """Gradient accumulation with FlatAdamW: the head kernels write a gradient straight into the optimiser's flat slot
+    only while ``param.grad`` is unset; a second backward() before step() must ADD (g1 + g2), as torch.optim.AdamW's path does."""
+    from evals.models.probes import DepthHead
+    from evals.utils.losses import DepthLoss
+    from mvp import functional as MF
+    from mvp.optim import FlatAdamW
+
+    g = torch.Generator().manual_seed(21)
+    feats = [torch.randn(2, 64, 6, 8, generator=g).to(dev) for _ in range(4)]
+    feats2 = [torch.randn(2, 64, 6, 8, generator=g).to(dev) for _ in range(4)]
+    tgt = (torch.rand(2, 1, 48, 64, generator=g) * 9 + 0.05).to(dev)
+
+    def make():
+        torch.manual_seed(5)
+        return DepthHead(feat_dim=[64] * 4, head_type="linear", kernel_size=1, prediction_type="bindepth", min_depth=0.001, max_depth=10).to(dev)
+
+    def two_backwards(probe):
+        for f in (feats, feats2):
+            pred = MF.interpolate(probe(f), size=tgt.shape[-2:], mode="bilinear")
+            DepthLoss()(pred, tgt.clone()).backward()
+
+    pa, pb = make(), make()
+    oa = FlatAdamW([{"params": pa.parameters(), "lr": 1e-3}])
+    ob = torch.optim.AdamW(pb.parameters(), lr=1e-3)
+    oa.zero_grad(); ob.zero_grad()
+    two_backwards(pa); two_backwards(pb)
+    ga = [p.grad.detach().clone() for p in pa.parameters()]
+    gb = [p.grad.detach().clone() for p in pb.parameters()]
+    for a, b in zip(ga, gb):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+    oa.step(); ob.step()
+    torch.cuda.synchronize()
+    for a, b in zip(pa.parameters(), pb.parameters()):
+        assert rel_l2(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6

@@ -114,6 +114,26 @@ def test_mae_hidden_state_taps_and_sincos(dev):
     assert rel_l2(out[0].cpu().numpy(), ovit.tokens_to_output("dense", bn0[:, 1:], None, (6, 8)).numpy()) < 1e-3
 
 
+def test_mae_wrapper_vs_hf_vitmae_golden(dev):
+    """The GPU MAE wrapper loaded from an HF-keyed state dict (transformers 4.29.2 names, as a local vit-mae checkpoint holds them)
+    against transformers' own ViTMAE encoder (golden mae_tiny.npz, see tests/golden/make_goldens.py::golden_mae): the four
+    tap maps (train-mode BatchNorm1d over the block INPUTS, quirk Q4) <= 1e-3 rel-L2; forward() rebuilds the sincos table for the
+    96 x 96 input (resize_pos_embed), which the golden's HF table pins."""
+    from conftest import load_golden
+    from evals.models.mae import MAE
+
+    g = load_golden("mae_tiny.npz")
+    sd = {k[2:]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith("w:")}
+    m = MAE(return_multilayer=True, add_norm=True, weights=sd).to(dev)
+    assert m.multilayers == [int(v) for v in g["multilayers"]] and m.heads == int(g["heads"])
+    out = m(torch.from_numpy(np.array(g["images"])).to(dev))
+    assert (m.feat_h, m.feat_w) == (6, 6)
+    assert np.abs(m.vit.pos_embed.detach().cpu().numpy() - g["pos_embed_hf"]).max() < 1e-6
+    for j, o in enumerate(out):
+        assert o.shape == g[f"dense_{j}"].shape
+        assert rel_l2(o.cpu().numpy(), g[f"dense_{j}"]) < 1e-3, j
+
+
 def test_mocov3_forced_resize(dev):
     from evals.models.mocov3 import MoCoV3
     from oracle import vit as ovit

@@ -53,6 +53,30 @@ def test_vit_base_224_samples():
         assert abs(taps[i].norm().item() - m[3]) / m[3] < 1e-5
 
 
+def _mae_golden_fused_weights(g):
+    """The golden's HF ViT-MAE weights (stored under the transformers 4.29.2 key names) in the fused DINO-style layout."""
+    from mvp import backbone as bb
+
+    return bb.hf_vitmae_to_fused({k[2:]: T(g[k]) for k in g.files if k.startswith("w:")})
+
+
+def test_mae_vs_hf_vitmae_golden():
+    """oracle/vit.py with the MAE settings (LayerNorm eps 1e-12, taps = block INPUTS: HF hidden_states indexing, quirk Q4; fixed
+    sincos pos-embed) against transformers' own ViTMAE encoder layers driven the way evals/models/mae.py:91-104,203-237 drives them
+    (golden mae_tiny.npz; generator: tests/golden/make_goldens.py::golden_mae, which states the 5.15-vs-4.29.2 caveat).  Also pins
+    the sincos table the wrapper rebuilds in resize_pos_embed to HF's own initialisation."""
+    g = load_golden("mae_tiny.npz")
+    sd = _mae_golden_fused_weights(g)
+    heads, layers = int(g["heads"]), [int(v) for v in g["multilayers"]]
+    images = T(g["images"])
+    assert np.abs(ovit.sincos_pos_embed_2d(128, (6, 6), True).numpy() - g["pos_embed_hf"][0]).max() < 1e-6
+    toks = ovit.vit_dense_features(sd, images, layers, heads=heads, add_norm=False, ln_eps=1e-12, pos_mode="fixed", tap_input_of_block=True, return_tokens=True)
+    dense = ovit.vit_dense_features(sd, images, layers, heads=heads, ln_eps=1e-12, pos_mode="fixed", tap_input_of_block=True)
+    for j in range(4):
+        assert rel_l2(toks[j].numpy(), g[f"tokens_{j}"]) < TOL, j
+        assert rel_l2(dense[j].numpy(), g[f"dense_{j}"]) < TOL, j
+
+
 def test_center_padding_quirk():
     x = torch.ones(1, 3, 32, 35)
     y = ovit.center_padding(x, 16)
