@@ -543,6 +543,27 @@ def main():
         cdt = time.perf_counter() - t0
         cpu = {"value": round(Bc * args.cpu_steps / cdt, 3), "unit": "images/s", "cores": cores, "kind": "port",
                "sample": f"{args.cpu_steps} steps of B={Bc} {H}x{W} (same step: extract 4 taps + linear bindepth probe + DepthLoss + backward + AdamW), 1 warm-up step, torch {torch.__version__} CPU fp32"}
+        # BASELINE.md §3's other points, on bounded samples: B = 8 (config #1's batch) on all cores — extract only and the whole step —
+        # and one thread (a single scalar-port core, the "cores: 1" reading of the same path)
+        variants = {}
+        ci8, ct8 = otrain.synthetic_depth_batch(8, H, W, rank=0, step=100)
+        tr.step(ci8, ct8.clone())
+        t0 = time.perf_counter()
+        for s_ in range(3):
+            tr.features(ci8)
+        variants["extract_only_B8"] = {"value": round(8 * 3 / (time.perf_counter() - t0), 3), "cores": cores, "sample": "3 frozen forwards (4 taps) of B=8"}
+        t0 = time.perf_counter()
+        for s_ in range(3):
+            tr.step(ci8, ct8.clone())
+        variants["step_B8"] = {"value": round(8 * 3 / (time.perf_counter() - t0), 3), "cores": cores, "sample": "3 steps of B=8, 1 warm-up"}
+        torch.set_num_threads(1)
+        ci1, ct1 = otrain.synthetic_depth_batch(2, H, W, rank=0, step=200)
+        tr.step(ci1, ct1.clone())  # warm-up at one thread
+        t0 = time.perf_counter()
+        tr.step(ci1, ct1.clone())
+        variants["step_1thread"] = {"value": round(2 / (time.perf_counter() - t0), 3), "cores": 1, "sample": "1 step of B=2 on one thread, 1 warm-up"}
+        torch.set_num_threads(cores)
+        cpu["variants"] = variants
 
     # ---------------- BASELINE config #1 (CPU-only by definition): DINO ResNet-50 random-init, single last-stage tap, 8 x 224 x 224
     # -> internally resized to 480^2 -> [8, 2048, 15, 15]; the oracle port of that path on the host cores, bounded sample

@@ -231,7 +231,6 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
   static_assert(WN == 64 && NT == 4 && (MT % 2) == 0, "wave tile 32k x 64");
   constexpr int EPW = WN + 4;                 // padded scratch row, floats
   constexpr int EP_BYTES = 32 * EPW * 4;      // per wave
-  constexpr int NIT = 4;                      // 8 rows per wave-instruction, 32 rows per chunk
   const int frow = lane & 15, fq = lane >> 4;
   float* ep = (float*)(smem + wave * EP_BYTES);
   const int er = lane >> 3, ec = (lane & 7) * 8;
@@ -248,11 +247,15 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
     const int gidx = m / p.row_group;
     return gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
   };
-  float4 rpre[NIT][2];
-  auto load_res = [&](int h) {
+  // Work unit = 16 rows (2 wave-instructions of 8 rows): small enough that the kernel's register allocation stays where the main loop
+  // put it (the whole 32-row chunk in flight cost 40 more VGPRs: 255, i.e. no other wave can share the SIMDs with this kernel's two —
+  // the probe step's small kernels run beside the frozen forward and need that room).
+  constexpr int HIT = 2;
+  float4 rpre[HIT][2];
+  auto load_res = [&](int u) {  // residual rows of 16-row unit u (u = 0 .. MT - 1)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + wm0 + h * 32 + it * 8 + er;
+    for (int it = 0; it < HIT; ++it) {
+      const int m = m0 + wm0 + u * 16 + it * 8 + er;
       rpre[it][0] = rpre[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < p.M && col_ok) {
         const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : out_row(m);
@@ -270,45 +273,49 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int i = 0; i < NT; ++i) *(f32x4_t*)(ep + (jj * 16 + frow) * EPW + i * 16 + fq * 4) = acc[i][h * 2 + jj];
-    float v[NIT][8];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int lr = it * 8 + er;
-      const f32x4_t a = *(const f32x4_t*)(ep + lr * EPW + ec), b = *(const f32x4_t*)(ep + lr * EPW + ec + 4);
+    for (int hh = 0; hh < 2; ++hh) {
+      const int u = h * 2 + hh;
+      float v[HIT][8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + bias8[e]; v[it][4 + e] = b[e] + bias8[4 + e]; }
-      if (ACT == MVP_ACT_GELU) {
+      for (int it = 0; it < HIT; ++it) {
+        const int lr = hh * 16 + it * 8 + er;
+        const f32x4_t a = *(const f32x4_t*)(ep + lr * EPW + ec), b = *(const f32x4_t*)(ep + lr * EPW + ec + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
+        for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + bias8[e]; v[it][4 + e] = b[e] + bias8[4 + e]; }
+        if (ACT == MVP_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
+        }
+        if (RES) {
+          v[it][0] += rpre[it][0].x; v[it][1] += rpre[it][0].y; v[it][2] += rpre[it][0].z; v[it][3] += rpre[it][0].w;
+          v[it][4] += rpre[it][1].x; v[it][5] += rpre[it][1].y; v[it][6] += rpre[it][1].z; v[it][7] += rpre[it][1].w;
+        }
       }
-      if (RES) {
-        v[it][0] += rpre[it][0].x; v[it][1] += rpre[it][0].y; v[it][2] += rpre[it][0].z; v[it][3] += rpre[it][0].w;
-        v[it][4] += rpre[it][1].x; v[it][5] += rpre[it][1].y; v[it][6] += rpre[it][1].z; v[it][7] += rpre[it][1].w;
-      }
-    }
-    if (RES && h + 1 < MT / 2) load_res(h + 1);  // issued BEFORE this chunk's stores: its data never waits behind them
+      if (RES && u + 1 < MT) load_res(u + 1);  // issued BEFORE this unit's stores: its data never waits behind them
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + wm0 + h * 32 + it * 8 + er;
-      if (m >= p.M || !col_ok) continue;
-      const int orow = out_row(m);
-      if (F32OUT) {
-        float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
-        *(float4*)op = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-        *(float4*)(op + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
-      }
-      if (PAIR) {
-        uint32_t hh[4], ll[4];
+      for (int it = 0; it < HIT; ++it) {
+        const int m = m0 + wm0 + u * 16 + it * 8 + er;
+        if (m >= p.M || !col_ok) continue;
+        const int orow = out_row(m);
+        if (F32OUT) {
+          float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
+          *(float4*)op = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+          *(float4*)(op + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
+        }
+        if (PAIR) {
+          uint32_t hw[4], lw[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split2_bf16(v[it][2 * e], v[it][2 * e + 1], hh[e], ll[e]);
-        if (oilv) {
-          mvp_bf16* o = p.out_hi + (size_t)orow * p.ldob + ilv32_col(ncol);
-          *(u32x4_t*)o = u32x4_t{hh[0], hh[1], hh[2], hh[3]};
-          *(u32x4_t*)(o + 32) = u32x4_t{ll[0], ll[1], ll[2], ll[3]};
-        } else {
-          const size_t o = (size_t)orow * p.ldob + ncol;
-          *(u32x4_t*)(p.out_hi + o) = u32x4_t{hh[0], hh[1], hh[2], hh[3]};
-          if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{ll[0], ll[1], ll[2], ll[3]};
+          for (int e = 0; e < 4; ++e) split2_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
+          if (oilv) {
+            mvp_bf16* o = p.out_hi + (size_t)orow * p.ldob + ilv32_col(ncol);
+            *(u32x4_t*)o = u32x4_t{hw[0], hw[1], hw[2], hw[3]};
+            *(u32x4_t*)(o + 32) = u32x4_t{lw[0], lw[1], lw[2], lw[3]};
+          } else {
+            const size_t o = (size_t)orow * p.ldob + ncol;
+            *(u32x4_t*)(p.out_hi + o) = u32x4_t{hw[0], hw[1], hw[2], hw[3]};
+            if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{lw[0], lw[1], lw[2], lw[3]};
+          }
         }
       }
     }

@@ -85,3 +85,21 @@ def test_ctypes_structs_match_the_compiled_header():
     for cname, cls in names.items():
         assert so.mvp_sizeof(cname.encode()) == ctypes.sizeof(cls), (cname, so.mvp_sizeof(cname.encode()), ctypes.sizeof(cls))
     assert so.mvp_sizeof(b"nope") == -1
+
+
+def test_integration_md_binding_matches_the_header():
+    """INTEGRATION.md §3 shows the ctypes struct a maintainer would copy.  Execute exactly that snippet's class definition and hold its
+    size to the compiled header (mvp_sizeof) and its field names / order to mvp/lib.py's mirror: a field added to mvp_gemm_args without
+    updating the document fails here (boundary doc drift)."""
+    import ctypes as C
+
+    from mvp import lib
+
+    md = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    m = re.search(r"class GemmArgs\(C\.Structure\):.*?\n(    _fields_ = .*?\])\s*\n\s*#", md, flags=re.S)
+    assert m, "INTEGRATION.md: the GemmArgs binding snippet was not found"
+    ns = {"C": C, "_vp": C.c_void_p, "_i": C.c_int}
+    exec("class GemmArgs(C.Structure):\n" + m.group(1), ns)
+    doc = ns["GemmArgs"]
+    assert [f[0] for f in doc._fields_] == [f[0] for f in lib.GemmArgs._fields_]
+    assert C.sizeof(doc) == lib.load().mvp_sizeof(b"mvp_gemm_args") == C.sizeof(lib.GemmArgs)
