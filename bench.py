@@ -47,9 +47,9 @@ def pmc_traffic(kernel: str):
             per = json.load(f)["per_launch"]
     except (OSError, ValueError, KeyError, TypeError):
         return None, None
-    for k, v in per.items():
-        if k.startswith(kernel.rstrip(">")):
-            return v["hbm_bytes"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    hits = [v for k, v in per.items() if k.startswith(kernel.rstrip(">"))]
+    if hits:  # (several instantiations may share the prefix — operand-layout variants of one kernel: the one with the most dispatches)
+        return max(hits, key=lambda v: v.get("dispatches", 0))["hbm_bytes"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
     return None, None
 
 
@@ -58,14 +58,17 @@ def pmc_mfma_busy(kernel: str):
     import re
 
     path = _latest_profile("pmc_summary.txt")
+    best = (-1, None)
     try:
         for line in open(path):
             if line.startswith(kernel.rstrip(">")):
                 m = re.search(r"SQ_VALU_MFMA_BUSY_CYCLES=([0-9.e+]+)", line)
-                return float(m.group(1)) if m else None
+                n = re.search(r"n=\s*(\d+)", line)
+                if m and n and int(n.group(1)) > best[0]:
+                    best = (int(n.group(1)), float(m.group(1)))
     except (OSError, TypeError):
         return None
-    return None
+    return best[1]
 
 
 def live_pmc(extra_args):
@@ -88,7 +91,7 @@ def live_pmc(extra_args):
     me = os.path.abspath(__file__)
     acc = {}
     try:
-        for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"]):
+        for counters in (["FETCH_SIZE"], ["WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]):
             d = tempfile.mkdtemp(prefix="mvp_pmc_")
             cmd = [rp, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, me, *extra_args, "--pmc-child"]
             # own session: on a timeout the whole group (rocprofv3 wrapper AND the profiled python) is ended, nothing is left on the GPU
@@ -114,14 +117,21 @@ def live_pmc(extra_args):
                     c = e.setdefault(row["Counter_Name"], [0.0, 0])
                     c[0] += float(row["Counter_Value"])
                     c[1] += 1
+                    if row["Counter_Name"] == "GRBM_GUI_ACTIVE":  # the dispatch's duration under the same pass: the clock the chip held
+                        dsum = e.setdefault("_dur_ns", [0.0, 0])
+                        dsum[0] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                        dsum[1] += 1
             shutil.rmtree(d, ignore_errors=True)
     except Exception:
         return None
     out = {}
     for name, cs in acc.items():
         f = cs.get("FETCH_SIZE", [0.0, 1]); w = cs.get("WRITE_SIZE", [0.0, 1]); b = cs.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0, 1])
-        # gfx950: FETCH_SIZE is in KiB and reports half of wide coalesced reads (x2); WRITE_SIZE in KiB is exact
-        out[name] = {"hbm_bytes": round(2.0 * f[0] / max(f[1], 1) * 1024.0 + w[0] / max(w[1], 1) * 1024.0), "mfma_busy": b[0] / max(b[1], 1)}
+        ga = cs.get("GRBM_GUI_ACTIVE", [0.0, 0]); du = cs.get("_dur_ns", [0.0, 0])
+        # gfx950: FETCH_SIZE is in KiB and reports half of wide coalesced reads (x2); WRITE_SIZE in KiB is exact;
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS): / 8 = busy cycles of the dispatch
+        out[name] = {"hbm_bytes": round(2.0 * f[0] / max(f[1], 1) * 1024.0 + w[0] / max(w[1], 1) * 1024.0), "mfma_busy": b[0] / max(b[1], 1),
+                     "gui_cycles": (ga[0] / ga[1] / 8.0) if ga[1] else None, "dur_us": (du[0] / du[1] / 1e3) if du[1] else None}
     return out
 
 
@@ -488,25 +498,29 @@ def main():
         name = ("gemm_pp_kernel<" if tile.startswith("pp ") else "gemm_kernel<") if kind == "gemm" else "attention_kernel"
         full_name = (("gemm_pp_kernel<" + tile[3:] + ">") if tile.startswith("pp ") else f"gemm_kernel<{tile}>") if kind == "gemm" else "attention_kernel"
         default_wl = (B, H, W, args.precision, args.probe) == (16, 224, 224, "bf16x3", "linear")
-        traffic, traffic_src, busy = None, None, None
+        traffic, traffic_src, busy, gui, pdur = None, None, None, None, None
         if pmc_live:
             hit = [v for k, v in pmc_live.items() if k.startswith(name if tile.startswith("pp ") else full_name.rstrip(">"))]
             if hit:
                 best = max(hit, key=lambda v: v["mfma_busy"] or 0.0)  # (the instantiation that did the work: layout variants share the prefix)
                 traffic, busy, traffic_src = best["hbm_bytes"], best["mfma_busy"] or None, "live: rocprofv3 --pmc child passes of this invocation"
+                gui, pdur = best.get("gui_cycles"), best.get("dur_us")
         if traffic is None and default_wl:
             traffic, traffic_src = pmc_traffic(name if tile.startswith("pp ") else full_name)
             busy = pmc_mfma_busy(name if tile.startswith("pp ") else full_name)
             traffic_src = f"committed pass {traffic_src}"
         ka = groups_alone.get((kind, tile))
         sec_alone = (ka[1] / ka[2]) if ka else None
-        clk = 1.6e9 if tile.startswith("pp ") else 2.1e9  # clock the chip holds under this load (in-kernel s_memtime stamps vs wall time)
+        clk = 1.97e9 if tile.startswith("pp ") else 2.1e9  # clock the chip holds under this kernel when no GRBM_GUI_ACTIVE pass is at hand
         roofline = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4),
             "traffic": traffic, "traffic_unit": f"bytes/launch (memory-side, rocprofv3 PMC: FETCH_SIZE x2 + WRITE_SIZE; {traffic_src})",
-            "mfma_busy": None if busy is None else {"SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy,
-                                                    "frac_of_simd_cycles": round(busy / (1024 * (sec_alone or sec / cnt) * clk), 3),
-                                                    "note": f"PMC pass (see traffic_unit); 1024 SIMDs x launch duration alone on the chip x {clk / 1e9:.1f} GHz (the clock the chip holds under this kernel)"},
+            "mfma_busy": None if busy is None else (
+                {"SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy, "frac_of_simd_cycles": round(busy / (1024 * gui), 3), "clock_ghz_in_that_pass": round(gui / (pdur * 1e3), 3),
+                 "note": "same PMC pass: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); the clock = those cycles / the dispatch's duration in that pass"}
+                if gui and pdur else
+                {"SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy, "frac_of_simd_cycles": round(busy / (1024 * (sec_alone or sec / cnt) * clk), 3),
+                 "note": f"PMC pass (see traffic_unit); 1024 SIMDs x launch duration alone on the chip x {clk / 1e9:.2f} GHz (GRBM_GUI_ACTIVE / 8 / duration, profiles/r03_pmc_summary.txt)"}),
             "hbm_kernels": {k[1]: {"launches_per_step": round(v[2] / nrl, 2), "avg_us": round(v[1] / v[2] * 1e6, 2), "alg_mbytes_per_launch": round(v[0] / v[2] / 1e6, 2),
                                    "achieved_gbps": round(v[0] / v[1] / 1e9, 1), "frac_of_8TBps": round(v[0] / v[1] / 8e12, 3)} for k, v in hbm.items()},
             "kernel": full_name, "launches_per_step": round(cnt / nrl, 2), "avg_launch_us": round(sec / cnt * 1e6, 2),

@@ -263,49 +263,108 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attenti
 }
 
 // N <= 256: all keys / values of one (batch, head) resident in LDS, 8 waves = 256 query rows.
+//
+// Persistent over (batch, head) pairs (round 3): a workgroup takes pairs blockIdx.x, blockIdx.x + gridDim.x, ... and keeps a ring of
+// nkt + 1 tile slots in LDS, so that the NEXT pair's first K/V tile and its Q fragments are fetched while the current pair's tiles
+// 1 .. nkt-1 are computed, and the current pair's output stores drain under the next pair's first tile.  Why: with one workgroup of
+// 100+ KB per CU nothing overlapped a pair's memory phase — at B = 96 (1152 pairs, 4.5 per CU) the launch took 81 us of which 39 us
+// were staging + Q loads + stores with no tile computed at all (tools/attn_bench.py, ablation 5): 232 MB at 6 TB/s, then the MFMAs.
+//   slot(i, t) = (nkt * i + t) % (nkt + 1) for tile t of the workgroup's i-th pair: the slot pair i leaves unused is exactly pair
+//   i+1's slot 0, and pair i+1's tiles t >= 1 fall into slots pair i has finished with when the pair-boundary barrier is passed.
+// Per pair: [tile 0 resident, Q in registers] -> issue tiles 1.. (land under tile 0's compute) -> tile 0 -> vmcnt(0) + barrier ->
+// issue next pair's tile 0 + Q -> tiles 1.. -> vmcnt(0) (the prefetch, issued long before) -> output stores -> barrier.
 template <int SPLIT>
 __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_attention_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int STAGE = 2 * NARR * TILE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
   const int q0 = wave * 32;
-  const int nkt = (p.N + 63) >> 6;
-  const size_t rowbase = (size_t)b * p.N;
-  // 8 waves x 8 rows = one 64-key tile per pass.  Tile 0 and Q first; the other tiles (3/4 of the bytes at N = 197)
-  // are issued behind the first barrier and land while tile 0 is being computed.
-  attn_stage_piece<SPLIT>(p, rowbase, h, 0, wave * 8, smem, smem + NARR * TILE, lane);
-  AttnState<SPLIT> st;
-  attn_load_q<SPLIT>(st, p, rowbase, q0, h, lane);
+  const int nkt = (p.N + 63) >> 6, nslot = nkt + 1;
+  const int npair = p.B * p.H;
   const float cs = p.scale * 1.44269504088896340736f;
   const bool active = q0 < p.N;  // wave-uniform
+  const int g = lane >> 4, c16 = lane & 15;
+
+  auto stage_tile = [&](int bh, int kt, int slot) {  // 8 waves x 8 rows = one 64-key tile
+    const int b = bh / p.H, h = bh - b * p.H;
+    char* base = smem + slot * STAGE;
+    attn_stage_piece<SPLIT>(p, (size_t)b * p.N, h, kt * 64, wave * 8, base, base + NARR * TILE, lane);
+  };
+  bf16x8_t qn_hi[2][2], qn_lo[2][2];
+  auto fetch_q = [&](int bh) {  // Q fragments of this wave's 32 query rows (global -> registers)
+    const int b = bh / p.H, h = bh - b * p.H;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qrow = min(q0 + qt * 16 + c16, p.N - 1);
+      const size_t off = ((size_t)b * p.N + qrow) * p.ld_qkv + h * 64 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        qn_hi[qt][ks] = *(const bf16x8_t*)(p.qkv_hi + off + ks * 32);
+        if (SPLIT == 3) qn_lo[qt][ks] = *(const bf16x8_t*)(p.qkv_lo + off + ks * 32);
+      }
+    }
+  };
+
+  int bh = blockIdx.x;
+  if (bh >= npair) return;
+  stage_tile(bh, 0, 0);
+  fetch_q(bh);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int kt = 1; kt < nkt; ++kt) {
-    char* base = smem + kt * STAGE;
-    attn_stage_piece<SPLIT>(p, rowbase, h, kt * 64, wave * 8, base, base + NARR * TILE, lane);
+  AttnState<SPLIT> st;
+  for (int i = 0; bh < npair; ++i, bh += gridDim.x) {
+    const int b = bh / p.H, h = bh - b * p.H;
+    const size_t rowbase = (size_t)b * p.N;
+    const int s0 = (nkt * i) % nslot;  // slot of this pair's tile 0
+    // this pair's remaining tiles: their slots were released at the barrier that ended the previous pair
+    for (int kt = 1; kt < nkt; ++kt) stage_tile(bh, kt, (s0 + kt) % nslot);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        st.q_hi[qt][ks] = qn_hi[qt][ks];
+        if (SPLIT == 3) st.q_lo[qt][ks] = qn_lo[qt][ks];
+      }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) st.o_acc[a][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    st.m_run[0] = st.m_run[1] = -1e30f;
+    st.l_run[0] = st.l_run[1] = 0.f;
+    if (active && MVP_ATT_ABLATE != 5) {
+      const char* kb = smem + s0 * STAGE;
+      if (nkt == 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, 0, p.N, cs, lane);
+      else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, 0, p.N, cs, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles 1.. landed (and the previous pair's stores have left)
+    __syncthreads();
+    const int nbh = bh + gridDim.x;
+    if (nbh < npair) {  // the next pair's first tile into the one free slot, its Q into registers: under this pair's remaining tiles
+      stage_tile(nbh, 0, (s0 + nkt) % nslot);
+      fetch_q(nbh);
+    }
+    if (active) {
+      for (int kt = 1; kt < (MVP_ATT_ABLATE == 5 ? 0 : nkt); ++kt) {
+        const char* kb = smem + ((s0 + kt) % nslot) * STAGE;
+        if (kt == nkt - 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+        else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+      }
+    }
+    // The prefetch was issued a whole pair's worth of tiles ago: this wait is free.  It comes BEFORE the output stores on purpose —
+    // vmcnt retires in issue order, so a wait placed behind the stores would also wait for their round trip; issued after it, the
+    // stores drain under the next pair's first tile (whose vmcnt(0) covers them) and the barrier below does not hold them back.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (active) attn_store<SPLIT>(st, p, rowbase, q0, h, lane);
+    if (nbh < npair) __builtin_amdgcn_s_barrier();  // next pair: its tile 0 is resident for everybody; everybody is done with this pair's tiles
   }
-  if (active && MVP_ATT_ABLATE != 5) {
-    if (nkt == 1) attn_tile<SPLIT, true>(st, smem, smem + NARR * TILE, 0, p.N, cs, lane);
-    else attn_tile<SPLIT, false>(st, smem, smem + NARR * TILE, 0, p.N, cs, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (!active) return;  // no barrier follows
-  for (int kt = 1; kt < (MVP_ATT_ABLATE == 5 ? 0 : nkt); ++kt) {
-    const char* kb = smem + kt * STAGE;
-    if (kt == nkt - 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
-    else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
-  }
-  attn_store<SPLIT>(st, p, rowbase, q0, h, lane);
 }
 
 template <int SPLIT>
 int launch_attention(const mvp_attention_args* a, hipStream_t s) {
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int STAGE = 2 * NARR * TILE;
-  constexpr int SMEM_STREAM = 2 * STAGE, SMEM_RES = 4 * STAGE;
+  constexpr int SMEM_STREAM = 2 * STAGE, SMEM_RES = 5 * STAGE;  // resident kernel: ring of nkt + 1 <= 5 tile slots (160 KiB at bf16x3)
   static int configured = [] {
     int e = (int)hipFuncSetAttribute((const void*)attention_stream_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_STREAM);
     if (e == 0) e = (int)hipFuncSetAttribute((const void*)attention_resident_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_RES);
@@ -314,7 +373,15 @@ int launch_attention(const mvp_attention_args* a, hipStream_t s) {
   if (configured != 0) return MVP_ELAUNCH;
   if (a->N <= 256) {
     const int nkt = (a->N + 63) >> 6;
-    hipLaunchKernelGGL((attention_resident_kernel<SPLIT>), dim3(a->B * a->H), dim3(512), nkt * STAGE, s, *a);
+    // persistent: one workgroup per CU-sized share of LDS (ring of nkt + 1 slots), pairs dealt round-robin
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+      return n > 0 ? n : 256;
+    }();
+    const int per_cu = (160 * 1024) / ((nkt + 1) * STAGE) > 0 ? (160 * 1024) / ((nkt + 1) * STAGE) : 1;
+    const int grid = a->B * a->H < cus * per_cu ? a->B * a->H : cus * per_cu;
+    hipLaunchKernelGGL((attention_resident_kernel<SPLIT>), dim3(grid), dim3(512), (nkt + 1) * STAGE, s, *a);
   } else {
     dim3 grid((a->N + 127) / 128, a->B * a->H);
     hipLaunchKernelGGL((attention_stream_kernel<SPLIT>), grid, dim3(256), SMEM_STREAM, s, *a);

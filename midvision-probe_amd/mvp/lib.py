@@ -312,5 +312,17 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+# Diagnostic hook (tools/micro/chain_timeline.py): when a list is installed, EVERY entry-point call is bracketed by HIP events recorded on
+# the stream it is launched on -> (name, stream, start event, end event).  None in production.
+TRACE_CALLS = None
+
+
 def call(name: str, args: C.Structure) -> None:
+    if TRACE_CALLS is None:
+        check(getattr(load(), name)(C.byref(args), stream_ptr()), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(getattr(load(), name)(C.byref(args), stream_ptr()), name)
+    e1.record()
+    TRACE_CALLS.append((name, stream_ptr(), e0, e1))

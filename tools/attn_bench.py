@@ -9,15 +9,19 @@ import torch
 from mvp import lib, ops
 
 CS = os.path.join(REPO, "midvision-probe_amd", "csrc")
-OUT = os.path.join(REPO, "gpurun_out")
+OUT = os.path.join(REPO, "tools", "micro")  # built in the build container, travels with the tree
 os.makedirs(OUT, exist_ok=True)
 
 
 def build(ablate, extra="", src=None, tag=""):
     so = os.path.join(OUT, f"libattn_ab{ablate}{tag}.so")
     src = src or f"{CS}/attention.hip"
-    cmd = f"/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I{REPO}/include -I{CS} -DMVP_ATT_ABLATE={ablate} {extra} {src} -o {so}"
-    subprocess.run(cmd, shell=True, check=True)
+    so = so.replace(".so", extra.replace(" ", "").replace("-D", "_").replace("=", "") + ".so")
+    # the product's flags (csrc/Makefile print-cxxflags: no packed fp32, no SLP vectoriser), so that what is timed is what ships
+    fl = subprocess.run(["make", "-s", "-C", CS, "print-cxxflags"], capture_output=True, text=True, check=True).stdout.strip().replace("-I../../include", f"-I{REPO}/include")
+    cmd = f"set -o pipefail; /opt/rocm/bin/hipcc {fl} -w -shared -I{CS} -DMVP_ATT_ABLATE={ablate} {extra} {src} -o {so} 2>&1 | {{ grep -v 'recognized feature' || true; }}"
+    if not os.path.exists(so):  # (reused when already built in the build container)
+        subprocess.run(["bash", "-c", cmd], check=True)
     l = C.CDLL(so)
     l.mvp_attention_fwd.argtypes = [C.POINTER(lib.AttentionArgs), C.c_void_p]
     l.mvp_attention_fwd.restype = C.c_int
@@ -30,6 +34,8 @@ def main():
     prev = os.path.join(REPO, "tools", "micro", "attention_prev.hip")
     if "--ab" in sys.argv and os.path.exists(prev):  # A/B against a saved earlier version of the kernel
         variants = {"full": build(0), "prev": build(0, src=prev, tag="_prev")}
+    # (tried in round 3 and dropped: delaying waves 4-7 of the resident kernel by 8 .. 48 x 64 cycles so that SIMD partners run out of
+    # phase — 77.8 us -> 77.6 .. 80.4 at B = 96, 16.7 -> 16.8 .. 17.1 at B = 16: nothing)
     dev = torch.device("cuda")
     B = int(os.environ.get("B", 16)); H = 12
     for N in (197, 785, 1201):
