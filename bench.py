@@ -158,6 +158,7 @@ def parse_args():
                          "'shared' with --inflight 1 runs the pipelined run's kernels as one serial chain (profiling)")
     ap.add_argument("--group", type=int, default=None, help="batches stacked into one frozen forward (default: mvp.pipeline.default_group)")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra inflight=1 leg reported as pipeline.serial (profiling runs)")
+    ap.add_argument("--prediction", default="bindepth", choices=["bindepth", "sigdepth"], help="bindepth = headline (256 bins); sigdepth = the reference's other depth predictor (secondary line)")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
     return ap.parse_args()
 
@@ -272,10 +273,10 @@ def main():
     def make_probe():
         torch.manual_seed(0)
         if args.probe == "linear":
-            pr = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth",
+            pr = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type=args.prediction,
                            min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
         else:
-            pr = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type="bindepth", hidden_dim=512,
+            pr = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type=args.prediction, hidden_dim=512,
                            min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
         # N > 1: rank 0's probe is broadcast at construction (DDP semantics); the flat-gradient all-reduce of step t runs
         # under the frozen forward of step t+1 and its AdamW update lands right before the probe forward
@@ -611,7 +612,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16x3 (split-bf16 MFMA, fp32 accumulate; fp32 residual/LN/softmax/loss)" if args.precision == "bf16x3" else "bf16 (MFMA, fp32 accumulate)",
             "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",
-            "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(" + ("linear,k=1" if args.probe == "linear" else "dpt,k=3,hidden512") + ",bindepth) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",
+            "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(" + ("linear,k=1" if args.probe == "linear" else "dpt,k=3,hidden512") + f",{args.prediction}) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
                        "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
             "mean_loss": round(last_loss, 5),

@@ -34,6 +34,8 @@ def main():
     prev = os.path.join(REPO, "tools", "micro", "attention_prev.hip")
     if "--ab" in sys.argv and os.path.exists(prev):  # A/B against a saved earlier version of the kernel
         variants = {"full": build(0), "prev": build(0, src=prev, tag="_prev")}
+        for n in os.environ.get("SGB", "").split():  # the interleave ratio of the streaming kernel's S(t+1) / softmax(t) block
+            variants[f"sgb{n}"] = build(0, extra=f"-DMVP_ATT_SGB={n}")
     # (tried in round 3 and dropped: delaying waves 4-7 of the resident kernel by 8 .. 48 x 64 cycles so that SIMD partners run out of
     # phase — 77.8 us -> 77.6 .. 80.4 at B = 96, 16.7 -> 16.8 .. 17.1 at B = 16: nothing)
     dev = torch.device("cuda")
