@@ -157,6 +157,7 @@ def parse_args():
                     help="GEMM tile policy (mvp_gemm_args.tile_policy): auto = what the pipeline selects (shared-chip 128x128 tiles from 3 forwards in flight); "
                          "'shared' with --inflight 1 runs the pipelined run's kernels as one serial chain (profiling)")
     ap.add_argument("--group", type=int, default=None, help="batches stacked into one frozen forward (default: mvp.pipeline.default_group)")
+    ap.add_argument("--span", type=int, default=None, help="images per frozen forward when forwards may end inside a batch (default: mvp.pipeline.default_span; 0 = whole batches only)")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the extra inflight=1 leg reported as pipeline.serial (profiling runs)")
     ap.add_argument("--prediction", default="bindepth", choices=["bindepth", "sigdepth"], help="bindepth = headline (256 bins); sigdepth = the reference's other depth predictor (secondary line)")
     ap.add_argument("--probe", default="linear", choices=["linear", "dpt"], help="linear = headline (k=1 bindepth); dpt = configs/probe/depth_dpt.yaml")
@@ -239,6 +240,8 @@ def main():
             wl += ["--inflight", str(args.inflight)]
         if args.group is not None:
             wl += ["--group", str(args.group)]
+        if args.span is not None:
+            wl += ["--span", str(args.span)]
         pmc_live = live_pmc(wl)  # before this process makes any GPU call
     from mvp import dist as mdist
 
@@ -309,10 +312,10 @@ def main():
     # forwards in flight: --inflight (None = the trainers' default: mvp.pipeline.default_depth / default_group), --group batches per forward
     d0 = default_depth(probe)
     pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else (d0 if (d0 == 1 or os.environ.get("MVP_INFLIGHT") is not None) else None),
-                           group=args.group)
+                           group=args.group, span=args.span)
     pipe.resolve_group(batches[0][0])
     if args.pmc_child:
-        args.warmup, args.steps = pipe.group, 2 * pipe.group
+        args.warmup, args.steps = pipe.group, ((2 * pipe.span) // B if pipe.span else 2 * pipe.group)  # about two full forwards of the timed run's shape
     if args.tiles == "alone" and pipe.chains >= SHARED_TILES_FROM:
         raise SystemExit("--tiles alone contradicts --inflight >= 3 (the pipeline selects the shared-chip tiles)")
     # the tile policy of the timed run's backbone GEMMs; a serial chain (--inflight 1) can be forced to it for profiling
@@ -374,7 +377,7 @@ def main():
     images_per_s = world * B * args.steps / dt
 
     # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
-    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": ("large-M 256x256 ping-pong kernel (gemm_pp.hip)" if pipe.group > 1 else "shared-chip (128x128)" if tiles_shared else "alone"),
+    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "span_images": (pipe.span or None), "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": ("large-M 256x256 ping-pong kernel (gemm_pp.hip)" if pipe.group > 1 else "shared-chip (128x128)" if tiles_shared else "alone"),
                      "what": "frozen forwards of upcoming batches (stacked `group` at a time into one chain of launches: same bits per batch) run on side "
                              "HIP streams under the probe steps of the current batches; every step still runs its own full forward + probe "
                              "forward/backward/AdamW inside the timed region, and the pipeline is empty at both of its barriers"}
@@ -457,8 +460,8 @@ def main():
         # every rank runs these extra steps (the optimiser step holds the gradient all-reduce); rank 0 reports
         i_rl = args.warmup + args.steps
         if pipe.depth > 1:
-            eager = FeaturePipeline(model, pipe.depth, graphs=False, group=pipe.group, streams=pipe.chains)
-            nrl = 2 * pipe.group
+            eager = FeaturePipeline(model, pipe.depth, graphs=False, group=pipe.group, streams=pipe.chains, span=pipe.span)
+            nrl = (2 * pipe.span) // B if pipe.span else 2 * pipe.group
         else:
             eager, nrl = FeaturePipeline(model, 1), 3
         run_steps(i_rl, nrl, None, eager)  # (allocates the eager pipeline's slot buffers)
@@ -473,10 +476,18 @@ def main():
         nalone = 0
         if pipe.depth > 1:  # forwards only, one after the other: every kernel alone on the chip
             for _ in range(2):
-                eager.submit_group([batches[i % n_distinct][0] for i in range(pipe.group)])
-                for _ in range(pipe.group):
+                if pipe.span:  # one full span from a batch boundary (the last batch cut)
+                    T = pipe.span
+                    pieces = [batches[i % n_distinct][0] for i in range(-(-T // B))]
+                    pieces[-1] = pieces[-1][:T - (len(pieces) - 1) * B]
+                    eager.submit_span(pieces, B, 0)
+                    nb = T // B
+                else:
+                    eager.submit_group([batches[i % n_distinct][0] for i in range(pipe.group)])
+                    nb = pipe.group
+                for _ in range(nb):
                     eager.next()
-                nalone += pipe.group
+                nalone += nb
             eager.drain()
         barrier()
         ops.set_trace(None)

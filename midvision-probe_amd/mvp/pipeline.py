@@ -26,6 +26,14 @@ except the tap BN, whose train-mode statistics belong to ONE batch (dino.py:185-
 batch's rows, and its running-statistics updates are applied per batch, in batch order, when the batch is handed over.  Each batch
 therefore gets exactly the bits it would get alone (tests/test_gpu_pipeline.py); the probe steps still run one batch at a time, in
 order, as train_depth.py:99-143 does.
+
+Spans (round 3).  Whole batches quantise badly: 6 batches are 74 row tiles x 3 column tiles = 222 workgroups on 256 CUs (87 % of a
+round), 7 batches are 261 (two rounds).  A forward may therefore cover a SPAN of the image stream that ends in the middle of a batch:
+110 images = 21 670 rows = 85 x 3 = 255 tiles of the same round (tools/micro/fwd_rows.py: 10.18 ms for 96 images, 10.59 for 104,
+10.99 for 110, 14.5 for 111); at 480x640 (1201 rows per image) 18 images instead of 16.  The engine keeps the tap-level rows of the
+cut batch and completes it in the next span's forward (ViTEngine.forward_taps, ``Span``): the tap BN still sees exactly one batch's
+16 images, so every batch still gets the bits it would get alone.  The carry (images of the cut batch already done) cycles through
+B / gcd(T, B) values; one graph per (slot, carry) pattern is captured at the pipeline's first submit.
 """
 from __future__ import annotations
 
@@ -35,6 +43,8 @@ import os
 from typing import Iterable, Iterator, Tuple
 
 import torch
+
+Span = collections.namedtuple("Span", "batch carry")  # a forward over a span of the image stream: images per batch, images of the cut batch carried in
 
 _SLOT = 0  # slot of the forward being enqueued (host state; kernels are enqueued by one host thread)
 _GROUPS = 1  # batches stacked into the forward being enqueued
@@ -48,8 +58,9 @@ def current_slot() -> int:
     return _SLOT
 
 
-def current_groups() -> int:
-    """Number of equal batches stacked along dim 0 of the forward being enqueued (1 outside a grouped pipeline forward)."""
+def current_groups():
+    """Number of equal batches stacked along dim 0 of the forward being enqueued (1 outside a grouped pipeline forward), or the
+    ``Span`` the forward covers."""
     return _GROUPS
 
 
@@ -168,6 +179,44 @@ def default_group(model, images: torch.Tensor, depth: int) -> int:
     return max(1, min(MAX_GROUP, int(round(GROUP_ROWS / rows))))
 
 
+MAX_SPAN_PATTERNS = 16  # (slot, carry) patterns whose graphs are captured up front; a span length with more runs eagerly
+
+
+def default_span(model, images: torch.Tensor, depth: int, group: int) -> int:
+    """IMAGES per forward when forwards may end in the middle of a batch (0: whole batches only).  MVP_PIPELINE_SPAN wins when set.
+    As many images as keep the narrowest GEMM of a block (N = C columns: ceil(C / 256) column tiles of the 256x256 kernel) within
+    one round of 256 CUs, rounded down to a multiple of B / 8 (few carry patterns); 0 when that is a whole number of batches anyway
+    (then ``group`` covers it), less than one batch, or the pipeline is not the two-slot one."""
+    env = os.environ.get("MVP_PIPELINE_SPAN")
+    B = images.shape[0]
+    ok = getattr(model, "supports_grouping", None)
+    if depth != 2 or ok is None or not ok() or (env is not None and int(env) <= 0):
+        return 0
+    if env is not None:
+        T = int(env)
+    else:
+        eng = model.engine() if hasattr(model, "engine") else None
+        C = int(getattr(eng, "C", 0) or 0)
+        if C <= 0:
+            return 0
+        P = int(getattr(model, "patch_size", 16))
+        H, W = images.shape[-2], images.shape[-1]
+        rows = 1 + (-(-H // P)) * (-(-W // P))
+        unit = max(1, B // 8)
+        T = min(((256 // (-(-C // 256))) * 256) // rows, MAX_GROUP * B) // unit * unit
+    return T if (T > B and T % B) else 0
+
+
+def span_patterns(T: int, B: int):
+    """(slot, carry) of consecutive span forwards of T images from a batch boundary, one full cycle (the slots alternate)."""
+    out, k = [], 0
+    while True:
+        out.append((k % 2, (k * T) % B))
+        k += 1
+        if (k * T) % B == 0 and k % 2 == 0:
+            return out
+
+
 def _tensors(obj):
     if torch.is_tensor(obj):
         yield obj
@@ -197,7 +246,7 @@ class FeaturePipeline:
     that no capture falls into the run); a ragged last group runs eagerly.
     A graph is tied to the engine it was captured from (rebuilt weights invalidate it: new key, new capture)."""
 
-    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None, group: int = 1):
+    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None, group: int = 1, span: int = None):
         """``run_ahead``: the host may be at most this many forwards ahead of the device (MVP_RUN_AHEAD, default 8; 0 = unbounded).
         The reference's loop syncs every step (``loss.item()``, train_depth.py:143); a loop that never syncs would otherwise queue
         hundreds of launches (and keep their argument buffers alive).  Throughput-neutral on MI355X (tools/micro/pipeline_probe.py,
@@ -212,6 +261,9 @@ class FeaturePipeline:
         self.group = None if group is None else max(1, int(group))  # resolved at the first submit (needs the batch shape)
         if self.depth == 1:
             self.group = 1
+        # images per span forward (module docstring, "Spans"): None = default_span when ``group`` is chosen automatically, else off
+        self._span_arg = span
+        self.span, self.span_batch, self._span_resolved = 0, 0, False
         # (stream priorities do not help: the device offers only (0, -1), and high-priority side streams measured the same)
         # ``depth`` forwards are submitted ahead (one buffer slot each); they run on ``streams`` side streams = kernel chains side by side
         self._streams_given = streams is not None or os.environ.get("MVP_PIPELINE_STREAMS") is not None
@@ -221,7 +273,7 @@ class FeaturePipeline:
         self.chains = max(1, min(depth, int(streams)))
         self.streams = [torch.cuda.Stream() for _ in range(self.chains)] if depth > 1 else []
         self._queue = collections.deque()  # one entry per BATCH: (features, completion event of its forward, deferred updates)
-        self._open = collections.deque()   # per forward in flight: batches of it not yet handed over
+        self._open = collections.deque()   # per forward in flight: [batches of it not yet handed over, its slot]
         self._n = 0
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
         self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
@@ -233,6 +285,7 @@ class FeaturePipeline:
         self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
         self._graphs = {}  # (slot, shape, dtype, training, engine id, group) -> dict(calls, graph, static_in, feats, deferred)
         self._stage = {}   # (slot, shape, dtype) -> stacked input buffer of eager grouped forwards
+        self._static = {}  # (slot, shape, dtype) -> static input buffer of that slot's graphs
 
     def __len__(self) -> int:
         """Batches submitted and not yet handed over."""
@@ -243,17 +296,36 @@ class FeaturePipeline:
         return self.depth - len(self._open)
 
     def resolve_group(self, images: torch.Tensor) -> int:
-        if self.group is None:
+        """Fix the shape of the forwards at the first submit (needs the batch shape): batches per group, images per span, slots, streams."""
+        if self._span_resolved:
+            return self.group
+        self._span_resolved = True
+        auto = self.group is None
+        depth_free = self._depth_arg is None and os.environ.get("MVP_INFLIGHT") is None
+        B = images.shape[0]
+        if auto:
             self.group = default_group(self.model, images, self.depth)
-            if self.group > 1 and self._depth_arg is None and os.environ.get("MVP_INFLIGHT") is None:
+        span = 0
+        if self.depth > 1 and (self.depth == 2 or depth_free) and not (self._streams_given and self._streams_arg != 1):
+            if self._span_arg is not None:
+                span = int(self._span_arg) if (int(self._span_arg) > B and int(self._span_arg) % B) else 0
+            elif auto:
+                span = default_span(self.model, images, 2, self.group)
+        if span:
+            # span forwards: two slots, ONE side stream (it orders the carry store between consecutive forwards)
+            self.span, self.span_batch = span, B
+            self.depth, self.chains = 2, 1
+            self.streams = self.streams[:1] if self.streams else [torch.cuda.Stream()]
+            self.group = max(self.group, -(-span // B))
+        elif auto and self.group > 1:
+            if depth_free:
                 # grouped forwards: two slots (one group being consumed, the next one's forward running); see default_depth
                 self.depth = 2
-            if self.group > 1:
-                # ... on ONE side stream unless asked otherwise: a grouped forward's GEMMs fill the chip by themselves (one 256x256 tile per
-                # CU), a second forward chain beside them adds nothing (measured, B = 16, 6 batches per forward, img/s at 20 / 60 steps:
-                # one stream 8357 / 8706, two 8326 / 8714), and one chain keeps every per-kernel measurement in the regime of the timed run
-                self.chains = max(1, min(self.depth, self._streams_arg if self._streams_given else 1))
-                self.streams = self.streams[:self.chains]
+            # ... on ONE side stream unless asked otherwise: a grouped forward's GEMMs fill the chip by themselves (one 256x256 tile per
+            # CU), a second forward chain beside them adds nothing (measured, B = 16, 6 batches per forward, img/s at 20 / 60 steps:
+            # one stream 8357 / 8706, two 8326 / 8714), and one chain keeps every per-kernel measurement in the regime of the timed run
+            self.chains = max(1, min(self.depth, self._streams_arg if self._streams_given else 1))
+            self.streams = self.streams[:self.chains]
         return self.group
 
     # ------------------------------------------------------------------ one forward on a slot's stream
@@ -263,50 +335,76 @@ class FeaturePipeline:
             feats = _extract(self.model, images)
             return feats, _take_deferred()
 
-    def _forward(self, slot: int, s, batches, G: int):
-        """Runs on stream ``s`` (current).  ``batches``: the G image batches of this forward.  Returns (features, deferred updates):
-        for G > 1 a GroupedFeatures and (batch index, update) pairs covering all its batches."""
+    def _forward(self, slot: int, s, batches, G):
+        """Runs on stream ``s`` (current).  ``batches``: the image tensors of this forward, stacked along dim 0 — G whole batches
+        (``G`` an int) or the pieces of a span (``G`` a ``Span``).  Returns (features, deferred updates): for G != 1 a GroupedFeatures
+        and (batch index, update) pairs covering all the batches the forward completes."""
         first = batches[0]
-        shape = (G * first.shape[0],) + tuple(first.shape[1:]) if G > 1 else tuple(first.shape)
-        full = G == self.group or G == 1 and self.group in (None, 1)
-        if not (self.graphs and full):
-            return self._eager(slot, self._stacked(slot, batches, shape) if G > 1 else first, G)
+        is_span = isinstance(G, Span)
+        shape = (sum(b.shape[0] for b in batches),) + tuple(first.shape[1:])
         eng = self.model.engine() if hasattr(self.model, "engine") else None
         key = (slot, shape, first.dtype, bool(self.model.training), id(eng), G)
-        ent = self._graphs.get(key)
-        if ent is None:
-            mine = [k for k in self._graphs if k[0] == slot]
-            for k in mine[:-1] if len(mine) >= 2 else []:  # at most two shapes per slot (full batches + an epoch's ragged last one)
-                del self._graphs[k]
-            ent = self._graphs[key] = dict(calls=0, graph=None)
+        if is_span:
+            # span forwards replay the graph of their (slot, carry) pattern when ``_precapture_spans`` set one up at the pipeline's first
+            # submit; anything else (a short span at the stream's end, a stream that restarted out of phase) runs eagerly rather than
+            # pay a capture — a device-wide sync — inside the run
+            ent = self._graphs.get(key) if self.graphs else None
+            if ent is None:
+                return self._eager(slot, self._stacked(slot, batches, shape), G)
+            ent["calls"] += 1
         else:
-            self._graphs[key] = self._graphs.pop(key)  # most recently used last
-        ent["calls"] += 1
-        if ent["graph"] is None and not any(e["graph"] is not None for e in self._graphs.values()):
-            # The very first forward of the pipeline: set up EVERY slot now (the set-up forwards write nothing but the slot's own buffers,
-            # their deferred updates are dropped), so that no capture — each one is a device-wide sync — falls into the run later,
-            # whatever the caller's warm-up length.  Later shapes (an epoch's ragged last batch) are set up lazily per slot.
-            for other in range(self.depth):
-                if other != slot:
-                    okey = (other,) + key[1:]
-                    oent = self._graphs[okey] = dict(calls=0, graph=None)
-                    self._capture(other, s, batches, shape, G, oent, eng)
-        if ent["graph"] is None:
-            return self._capture(slot, s, batches, shape, G, ent, eng)  # (its replay computed this forward's features)
+            full = G == self.group or G == 1 and self.group in (None, 1)
+            if not (self.graphs and full):
+                return self._eager(slot, self._stacked(slot, batches, shape) if G > 1 else first, G)
+            ent = self._graphs.get(key)
+            if ent is None:
+                mine = [k for k in self._graphs if k[0] == slot]
+                for k in mine[:-1] if len(mine) >= 2 else []:  # at most two shapes per slot (full batches + an epoch's ragged last one)
+                    del self._graphs[k]
+                ent = self._graphs[key] = dict(calls=0, graph=None)
+            else:
+                self._graphs[key] = self._graphs.pop(key)  # most recently used last
+            ent["calls"] += 1
+            if ent["graph"] is None and not any(e["graph"] is not None for e in self._graphs.values()):
+                # The very first forward of the pipeline: set up EVERY slot now (the set-up forwards write nothing but the slot's own
+                # buffers, their deferred updates are dropped), so that no capture — each one is a device-wide sync — falls into the run
+                # later, whatever the caller's warm-up length.  Later shapes (an epoch's ragged last batch) are set up lazily per slot.
+                for other in range(self.depth):
+                    if other != slot:
+                        okey = (other,) + key[1:]
+                        oent = self._graphs[okey] = dict(calls=0, graph=None)
+                        self._capture(other, s, batches, shape, G, oent, eng)
+            if ent["graph"] is None:
+                return self._capture(slot, s, batches, shape, G, ent, eng)  # (its replay computed this forward's features)
         self._fill(ent["static_in"], batches, G)
         ent["graph"].replay()
         for pk in ent["packs"]:
             pk.generation += 1  # the host code that counts rewrites of the packing does not run on a replay
         return ent["feats"], ent["deferred"]
 
-    @staticmethod
-    def _fill(dst: torch.Tensor, batches, G: int) -> None:
-        if G == 1:
-            dst.copy_(batches[0], non_blocking=True)
+    def _precapture_spans(self, s, sample: torch.Tensor) -> None:
+        """Capture the graph of every (slot, carry) pattern full spans cycle through, on copies of ``sample`` (results and deferred
+        updates dropped; the carry store they scribble on is not read before a real forward has written it)."""
+        T, B = self.span, self.span_batch
+        pats = span_patterns(T, B)
+        if len(pats) > MAX_SPAN_PATTERNS:
             return
-        B = batches[0].shape[0]
-        for g, b in enumerate(batches):
-            dst[g * B:(g + 1) * B].copy_(b, non_blocking=True)
+        filler = []
+        while sum(f.shape[0] for f in filler) < T:
+            filler.append(sample[:T - sum(f.shape[0] for f in filler)])
+        shape = (T,) + tuple(sample.shape[1:])
+        eng = self.model.engine() if hasattr(self.model, "engine") else None
+        for slot, carry in pats:
+            G = Span(B, carry)
+            ent = self._graphs[(slot, shape, sample.dtype, bool(self.model.training), id(eng), G)] = dict(calls=0, graph=None)
+            self._capture(slot, s, filler, shape, G, ent, eng)
+
+    @staticmethod
+    def _fill(dst: torch.Tensor, batches, G=None) -> None:
+        at = 0
+        for b in batches:
+            dst[at:at + b.shape[0]].copy_(b, non_blocking=True)
+            at += b.shape[0]
 
     def _stacked(self, slot: int, batches, shape) -> torch.Tensor:
         """The [G * B, ...] input of an eager grouped forward: a per-slot staging buffer (reused, so the steady state allocates nothing)."""
@@ -324,7 +422,10 @@ class FeaturePipeline:
         uploads it to the device: that cost belongs here, not in the run).  Returns the replay's (features, deferred updates)."""
         from .vit import lookup_pack
 
-        static_in = torch.empty(shape, dtype=batches[0].dtype, device=batches[0].device)
+        skey = (slot, tuple(shape), batches[0].dtype)  # one static input per slot and shape (a slot's span patterns share it)
+        static_in = self._static.get(skey)
+        if static_in is None:
+            static_in = self._static[skey] = torch.empty(shape, dtype=batches[0].dtype, device=batches[0].device)
         self._fill(static_in, batches, G)
         self._eager(slot, static_in, G)
         g = torch.cuda.CUDAGraph()
@@ -348,10 +449,27 @@ class FeaturePipeline:
         if G < 1:
             raise ValueError("empty group")
         self.resolve_group(batches[0])
-        if self.free_slots() <= 0:
-            raise RuntimeError(f"{self.depth} forwards already in flight: call next() first")
         if G > 1 and (any(b.shape != batches[0].shape or b.dtype != batches[0].dtype for b in batches) or self.depth == 1):
             raise ValueError("a grouped forward needs equal-shaped batches and a pipeline of depth >= 2")
+        self._submit(batches, G, G)
+
+    def submit_span(self, pieces, batch: int, carry: int) -> None:
+        """Enqueue ONE forward over a span of the image stream (module docstring, "Spans"): ``pieces`` = image tensors, consecutive in
+        the stream, whose first ``batch - carry`` images (when carry > 0) complete the batch the previous span cut; the span may end
+        inside a batch again.  ``next()`` hands over the (carry + images) // batch batches the forward completes, in order."""
+        pieces = list(pieces)
+        if not pieces or self.depth != 2 or self.chains != 1:
+            raise ValueError("a span forward needs images and the two-slot, one-stream pipeline of grouped forwards")
+        if any(p.shape[1:] != pieces[0].shape[1:] or p.dtype != pieces[0].dtype for p in pieces):
+            raise ValueError("a span forward needs equal-shaped images")
+        T = sum(p.shape[0] for p in pieces)
+        if not 0 <= carry < batch or (carry + T) // batch < 1:
+            raise ValueError(f"span of {T} images with carry {carry} completes no batch of {batch}")
+        self._submit(pieces, Span(int(batch), int(carry)), (carry + T) // batch)
+
+    def _submit(self, batches, G, nb: int) -> None:
+        if self.free_slots() <= 0:
+            raise RuntimeError(f"{self.depth} forwards already in flight: call next() first")
         if self.run_ahead > 0 and len(self._issued) >= self.run_ahead:
             self._issued.popleft().synchronize()  # host waits for the forward issued ``run_ahead`` submissions ago
         if self.depth == 1:
@@ -361,19 +479,30 @@ class FeaturePipeline:
                 ev.record()
                 self._issued.append(ev)
             self._queue.append((feats, None, ()))
-            self._open.append(1)
+            self._open.append([1, 0])
             return
+        is_span = isinstance(G, Span)
+        if is_span and not self._open and G.carry == 0:
+            self._n = 0  # a stream that (re)starts on a batch boundary starts the (slot, carry) cycle of the captured graphs over
+        # slots rotate — but never a slot whose previous forward still has batches to hand over
+        busy = {e[1] for e in self._open}
         slot = self._n % self.depth
+        if slot in busy:
+            slot = next(i for i in range(self.depth) if i not in busy)
         s = self.streams[self._n % len(self.streams)]
         self._n += 1
         cur = torch.cuda.current_stream()
         # the batches are ready on the caller's stream, and the probe steps that read this slot's buffers are already enqueued there
         s.wait_stream(cur)
         with torch.cuda.stream(s):
-            if self.graphs and self.group > 1 and G != self.group and not self._graphs:
-                # the pipeline's first forward is a ragged group (a warm-up shorter than a group): set the full-group graphs of all
-                # slots up NOW, on copies of this batch, so that no capture falls into the run later (their updates are dropped)
-                self._forward(slot, s, [batches[0]] * self.group, self.group)
+            if self.graphs and not self._graphs:
+                if is_span and self.span:
+                    # the pipeline's first forward: set the graphs of all full-span patterns up NOW, whatever this forward's length (a
+                    # warm-up is shorter than a span), so that no capture falls into the run later
+                    self._precapture_spans(s, batches[0])
+                elif not is_span and self.group > 1 and G != self.group:
+                    # the same for a ragged first group
+                    self._forward(slot, s, [batches[0]] * self.group, self.group)
             feats, deferred = self._forward(slot, s, batches, G)
             done = torch.cuda.Event()
             done.record(s)
@@ -385,16 +514,16 @@ class FeaturePipeline:
         if G == 1 and not isinstance(feats, GroupedFeatures):
             self._queue.append((feats, done, [fn for _, fn in deferred]))
         else:
-            if not isinstance(feats, GroupedFeatures) or len(feats) != G:
+            if not isinstance(feats, GroupedFeatures) or len(feats) != nb:
                 raise RuntimeError("the backbone did not return one result per batch of the group")
-            for g in range(G):
+            for g in range(nb):
                 self._queue.append((feats[g], done, [fn for gg, fn in deferred if gg == g]))
-        self._open.append(G)
+        self._open.append([nb, slot])
 
     def next(self):
         feats, done, deferred = self._queue.popleft()
-        self._open[0] -= 1
-        if self._open[0] == 0:
+        self._open[0][0] -= 1
+        if self._open[0][0] == 0:
             self._open.popleft()
         if done is not None:
             cur = torch.cuda.current_stream()
@@ -441,7 +570,8 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
         # mvp.prefetch.DevicePrefetcher recycles its device buffers (it sizes its pool when its first batch is pulled): this generator
         # holds up to depth x group batches before the caller has issued the probe step of the first of them (which reads that batch's
         # target; its image is read by the forward in flight).  The group size is not known before the first batch: its upper bound.
-        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth * (pipe.group or MAX_GROUP) - 1)
+        # (a span forward also holds the batch it cuts)
+        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth * ((pipe.group or MAX_GROUP) + (1 if (pipe.span or pipe.group is None) else 0)) - 1)
     it = iter(batches)
     pending = collections.deque()
     held = []  # a batch pulled from the iterator that did not fit the group being formed
@@ -461,11 +591,54 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
             return None
         return b, images_of(b)
 
+    cut = []  # [(batch, images, images of it already forwarded)]: the batch the previous span forward ended in
+
+    def feed_span() -> bool:
+        """One forward over the next ``pipe.span`` images of the stream (fewer at its end or where the batch shape changes)."""
+        B = pipe.span_batch
+        pieces, done, carry, room = [], [], 0, pipe.span
+        if cut:
+            b, x, used = cut.pop()
+            pieces.append(x[used:])  # (a span is longer than a batch: the cut batch always completes here)
+            done.append(b)
+            carry, room = used, room - (B - used)
+        while room > 0:
+            nxt = pull()
+            if nxt is None:
+                break
+            ref = pieces[0] if pieces else None
+            if nxt[1].shape[0] != B or (ref is not None and (nxt[1].shape[1:] != ref.shape[1:] or nxt[1].dtype != ref.dtype)):
+                held.append(nxt)  # (the span ends on a batch boundary here: a batch is only ever cut as the last piece)
+                break
+            if room >= B:
+                pieces.append(nxt[1])
+                done.append(nxt[0])
+                room -= B
+            else:
+                pieces.append(nxt[1][:room])
+                cut.append((nxt[0], nxt[1], room))
+                room = 0
+        if not pieces:
+            return False
+        if not done:  # part of one batch and nothing else (cannot happen: spans are longer than a batch): run the batch whole
+            b, x, _ = cut.pop()
+            pipe.submit_group([x])
+            pending.append(b)
+            return True
+        pipe.submit_span(pieces, B, carry)
+        pending.extend(done)
+        return True
+
     def feed() -> bool:
+        if cut:
+            return feed_span()
         first = pull()
         if first is None:
             return False
         G = pipe.resolve_group(first[1])
+        if pipe.span and first[1].shape[0] == pipe.span_batch:
+            held.append(first)
+            return feed_span()
         grp = [first]
         while len(grp) < G:
             nxt = pull()

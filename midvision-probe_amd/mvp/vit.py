@@ -148,12 +148,15 @@ class ViTEngine:
         self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
         self._packs: Dict[Tuple[int, int, int, int, int], PackedFeatures] = {}
         self._slot_outs: Dict[tuple, dict] = {}  # output maps of pipelined forwards, owned by the slot
+        self._carry: Dict[tuple, torch.Tensor] = {}  # (batch, gh, gw, taps) -> [taps, batch * N, C] tap-level rows of a batch cut by a span's end
         pipeline.publish()  # the split weights are read by forwards on any stream
 
     # ------------------------------------------------------------------ helpers
-    def _workspace(self, B: int, gh: int, gw: int) -> dict:
+    def _workspace(self, B: int, gh: int, gw: int, headroom: int = 0) -> dict:
         key = (B, gh, gw, pipeline.current_slot())
         ws = self._ws.get(key)
+        if ws is not None and ws["headroom"] < headroom:
+            ws = None
         if ws is None:
             N = 1 + gh * gw
             M = B * N
@@ -163,8 +166,9 @@ class ViTEngine:
             # k-step of a row is then one whole 128-byte line for the LDS-DMA (2-3 % per GEMM on top of the interleaved weights).
             ilv = (pr == PREC_BF16X3 and os.environ.get("MVP_ILV", "1") != "0" and C % 32 == 0 and self.hidden % 32 == 0 and
                    all(ops.gemm_tile(M, n, k, pr, 1, pipeline.tile_policy()).startswith("pp ") for n, k in ((3 * C, C), (C, C), (self.hidden, C), (C, self.hidden))))
+            xfull = torch.empty(M + headroom * N, C, dtype=torch.float32, device=dev)
             ws = dict(
-                x=torch.empty(M, C, dtype=torch.float32, device=dev),
+                xfull=xfull, headroom=headroom, x=xfull[headroom * N:],
                 xn=ops.IlvPair(M, C, dev) if ilv else ops.empty_pair((M, C), pr, dev),
                 qkv=ops.empty_pair((M, 3 * C), pr, dev),
                 ao=ops.IlvPair(M, C, dev) if ilv else ops.empty_pair((M, C), pr, dev),
@@ -209,8 +213,9 @@ class ViTEngine:
         self._pos.clear()
 
     # ------------------------------------------------------------------ forward
-    def tokens(self, images: torch.Tensor) -> Tuple[dict, int, int, int]:
-        """Patch-embed + CLS + pos-embed into ws['x'] (K1); returns (ws, B, gh, gw)."""
+    def tokens(self, images: torch.Tensor, headroom: int = 0) -> Tuple[dict, int, int, int]:
+        """Patch-embed + CLS + pos-embed into ws['x'] (K1); returns (ws, B, gh, gw).  ``headroom``: images' worth of rows kept free in
+        front of ws['x'] (ws['xfull'] = head-room + x; span forwards, see forward_taps)."""
         images = images.to(self.device, torch.float32).contiguous()
         B, Cin, H, W = images.shape
         P = self.patch
@@ -220,7 +225,7 @@ class ViTEngine:
         else:  # center_padding quirk: a non-ragged dim still gets a full patch (utils.py:55-72)
             ph, pw = P - rh, P - rw
         gh, gw = (H + ph) // P, (W + pw) // P
-        ws = self._workspace(B, gh, gw)
+        ws = self._workspace(B, gh, gw, headroom)
         N, C = 1 + gh * gw, self.C
         ops.patch_gather(images, ws["patches"], P, gh, gw, ph // 2, pw // 2)
         pos = self.pos_for(gh, gw, H + ph, W + pw)
@@ -252,12 +257,35 @@ class ViTEngine:
         ``groups`` = G > 1: ``images`` holds G batches of equal size stacked along dim 0 (mvp/pipeline.py).  Patch embedding,
         LayerNorm, the GEMMs and attention are per-row / per-image, so the G batches simply share their launches (M = G * B * N
         rows: the large-M GEMM kernel); the tap BN — train-mode statistics over ONE batch (dino.py:185-191) — runs per batch on that
-        batch's rows.  Every batch gets exactly the bits it would get alone; returns ``TapGroups`` (one ``TapOutputs`` per batch)."""
-        ws, Bt, gh, gw = self.tokens(images)
-        if groups < 1 or Bt % groups:
-            raise lib.MvpError(f"grouped forward: {Bt} images do not split into {groups} equal batches")
-        G, B = groups, Bt // groups
+        batch's rows.  Every batch gets exactly the bits it would get alone; returns ``TapGroups`` (one ``TapOutputs`` per batch).
+        ``groups`` = ``pipeline.Span(batch, carry)``: the forward's images are a SPAN of the image stream that need not start or end on
+        a batch boundary (batches of ``batch`` images; the first ``batch - carry`` images complete the batch whose first ``carry``
+        images ended the previous span, when carry > 0).  The blocks do not care; per tap, the carried images' rows (kept in
+        ``self._carry``, written by the previous span's forward on the same stream) are copied in FRONT of this span's rows — the
+        ``x`` workspace has that head-room — so that all complete batches are contiguous and one grouped tap-BN launch serves them, and
+        the rows of a trailing incomplete batch are copied to the carry store for the next span.  Returns ``TapGroups`` of the
+        (carry + images) // batch batches this forward completes."""
+        span = groups if isinstance(groups, pipeline.Span) else None
+        ws, Bt, gh, gw = self.tokens(images, headroom=span.batch if span else 0)
         N, C, hw = 1 + gh * gw, self.C, gh * gw
+        if span is not None:
+            B, carry = int(span.batch), int(span.carry)
+            if B < 1 or not 0 <= carry < B:
+                raise lib.MvpError(f"span forward: carry {carry} outside [0, {B})")
+            G, tail = (carry + Bt) // B, (carry + Bt) % B
+            if G < 1:
+                raise lib.MvpError(f"span forward: {carry} + {Bt} images complete no batch of {B}")
+            x_bn = ws["xfull"][(ws["headroom"] - carry) * N:]  # the complete batches: carried rows (copied per tap) + this span's rows
+            ckey = (B, gh, gw, len(list(layers)))
+            store = self._carry.get(ckey)
+            if store is None:
+                self._carry.clear()
+                store = self._carry[ckey] = torch.empty(len(list(layers)), B * N, C, dtype=torch.float32, device=self.device)
+        else:
+            if groups < 1 or Bt % groups:
+                raise lib.MvpError(f"grouped forward: {Bt} images do not split into {groups} equal batches")
+            G, B, carry, tail = groups, Bt // groups, 0, 0
+            x_bn = ws["x"]
         layers = list(layers)
         outs_g = [TapOutputs() for _ in range(G)]
         bn_ws = ws.get(("bn_ws", G))  # tap-BN partials + scale / shift of G batches of B * N rows
@@ -301,16 +329,20 @@ class ViTEngine:
         # different streams finish in any order, so a pipelined forward leaves that update to the consumer (pipeline.defer), which
         # applies it on the trainer's stream in batch order — same arithmetic, same bits (mvp_bn_running_update).
         defer = bn is not None and bn_mode == 0 and pipeline.pipelined()
-        if G > 1 and bn is not None and bn_mode == 0 and not defer:
+        if (G > 1 or span is not None) and bn is not None and bn_mode == 0 and not defer:
             raise lib.MvpError("a grouped forward with train-mode tap BN must run under the pipeline (its running-statistics updates are per batch)")
 
         def tap(j):
             b = bn[j] if bn is not None else None
             nchw, cls = out["nchw"][j], out["cls"][j]
             tok0 = packed_g[0].tok if pack else None
+            if carry:
+                x_bn[:carry * N].copy_(store[j, :carry * N])
+            if tail:
+                store[j, :tail * N].copy_(ws["x"][(Bt - tail) * N:Bt * N])
             # ONE call for all batches of the group: statistics, normalisation and outputs per batch (mvp_bn_tokens_args.groups)
             ops.bn_tokens_to_nchw(
-                ws["x"], B, N, C, hw, workspace=bn_ws, stats=out["stats"][0, j],
+                x_bn, B, N, C, hw, workspace=bn_ws, stats=out["stats"][0, j],
                 gamma=b["weight"] if b else None, beta=b["bias"] if b else None,
                 running_mean=b["running_mean"] if b else None, running_var=b["running_var"] if b else None,
                 nchw=nchw[0], tok=tok0, ld_tok=packed_g[0].Cpad if pack else 0, col_off=j * C,
@@ -340,7 +372,7 @@ class ViTEngine:
             if packed_g[g] is not None:
                 outs_g[g].packed = packed_g[g]
                 register_pack(outs_g[g], packed_g[g])
-        return outs_g[0] if G == 1 else TapGroups(outs_g)
+        return outs_g[0] if (G == 1 and span is None) else TapGroups(outs_g)
 
     def forward_tokens(self, images: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
         """Raw fp32 token stream after ``n_blocks`` blocks ([B, N, C]); for tests / CLS outputs."""

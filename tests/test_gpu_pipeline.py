@@ -402,6 +402,58 @@ def test_grouped_forwards_are_bit_identical_to_serial(group, depth, graphs):
     assert got[4] == ref[4] == [7] * 4
 
 
+@pytest.mark.parametrize("span,graphs,n", [(10, False, 9), (10, True, 9), (6, True, 8), (14, True, 12), (9, True, 13), (7, True, 11)])
+def test_span_forwards_are_bit_identical_to_serial(span, graphs, n):
+    """Forwards over SPANS of the image stream that end in the middle of a batch (mvp/pipeline.py, "Spans"): batches of 4 images,
+    ``span`` images per forward, so most forwards start with the rest of the batch the previous one cut (after 2 images for the even
+    spans; 9 and 7 cycle through all four cut positions).  The tap BN of that batch still runs over its own 4 images (the engine carries the cut batch's tap-level rows into the
+    next forward), so losses, probe weights, AdamW state, running statistics and step counters equal the one-batch-at-a-time loop's
+    (train_depth.py:99-143) bit for bit — through two legs of the same pipeline (the second leg restarts on a batch boundary), with
+    graph replay of the full spans and eager short ones."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+    ref = _run(1, n=n)
+    model, probe, opt, sched = _build(dev)
+    loss_fn = DepthLoss()
+    bs = _batches(dev, n)
+    pipe = FeaturePipeline(model, 2, graphs=graphs, group=-(-span // 4), span=span)
+    losses = []
+    for part in (bs[:3], bs[3:]):  # a warm-up leg shorter than two spans, then the rest
+        for b, f in pipelined_features(model, part, pipe=pipe):
+            losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, b["depth"].clone(), feats=f))
+    assert pipe.span == span and pipe.depth == 2 and pipe.chains == 1
+    if graphs:  # one graph per (slot, carry) pattern, all captured at the first submit
+        from mvp.pipeline import span_patterns
+        assert all(e["graph"] is not None for e in pipe._graphs.values())
+        assert sorted((k[0], k[-1].carry) for k in pipe._graphs) == sorted(span_patterns(span, 4))
+        assert sum(e["calls"] for e in pipe._graphs.values()) >= 1
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(torch.stack(losses).cpu().numpy(), ref[0])
+    np.testing.assert_array_equal(opt.flat_param.cpu().numpy(), ref[1])
+    np.testing.assert_array_equal(opt.exp_avg_sq.cpu().numpy(), ref[2])
+    for bnm, r in zip(model.batchnorms, ref[3]):
+        np.testing.assert_array_equal(torch.cat([bnm.running_mean, bnm.running_var]).cpu().numpy(), r)
+    assert [int(b.num_batches_tracked) for b in model.batchnorms] == [n] * 4
+
+
+def test_default_span_of_the_timed_configuration():
+    """B = 16 at 224^2 on ViT-B/16: 110 images per forward (21670 rows = 85 x 3 tiles of 256^2: one round of 256 CUs for the
+    N = 768 GEMMs); 480x640 (1201 rows per image): 18 images."""
+    from mvp.pipeline import FeaturePipeline
+
+    dev = torch.device("cuda:0")
+    model, _, _, _ = _build(dev)
+    pipe = FeaturePipeline(model, None, group=None)
+    pipe.resolve_group(torch.empty(16, 3, 224, 224, device=dev))
+    assert (pipe.group, pipe.depth, pipe.chains, pipe.span) == (7, 2, 1, 110)
+    pipe = FeaturePipeline(model, None, group=None)
+    pipe.resolve_group(torch.empty(16, 3, 480, 640, device=dev))
+    assert (pipe.group, pipe.depth, pipe.chains, pipe.span) == (2, 2, 1, 18)
+
+
 def test_warmup_shorter_than_a_group_sets_the_full_group_graphs_up():
     """bench.py's shape: a warm-up of fewer batches than one group, then full groups.  The full-group graphs of every slot are captured
     at the pipeline's FIRST submit (on copies of that batch, updates dropped), so the later full groups only replay."""
@@ -451,16 +503,18 @@ def test_timed_configuration_b16_224_grouped_graphs_vs_serial_and_oracle():
     host = [otrain.synthetic_depth_batch(B, 224, 224, rank=0, step=s) for s in range(n)]
     bs = [(i.to(dev), t.to(dev)) for i, t in host]
 
-    def run(depth, group, graphs):
+    def run(depth, group, graphs, span=0, keep=4):
         model = DINO(return_multilayer=True, add_norm=True, weights=vsd).to(dev)
         probe = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type="bindepth")
         probe.load_state_dict(psd, strict=True)
         probe = probe.to(dev)
         opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}])
-        pipe = FeaturePipeline(model, depth, graphs=graphs, group=group)
+        pipe = FeaturePipeline(model, depth, graphs=graphs, group=group, span=span)
+        pipe.resolve_group(bs[0][0])
+        assert pipe.span == span
         losses, kept = [], None
         for i, ((img, tgt), f) in enumerate(pipelined_features(model, bs, pipe=pipe)):
-            if i == 4:
+            if i == keep:
                 kept = [t.clone() for t in f]  # features of the fifth batch: inside the first group of six
             losses.append(train_depth_step(model, probe, opt, None, DepthLoss(), None, tgt.clone(), feats=f))
         torch.cuda.synchronize()
@@ -473,6 +527,16 @@ def test_timed_configuration_b16_224_grouped_graphs_vs_serial_and_oracle():
     for a, b in zip(got[2], ref[2]):
         np.testing.assert_array_equal(a, b)
     for a, b in zip(got[3], ref[3]):
+        np.testing.assert_array_equal(a, b)
+    # (c) the default of round 3's end: spans of 110 images (M = 21670 rows; forwards of 110 + 18 images here), the kept batch (the
+    # seventh) is the one the first span cuts (after 14 images)
+    ref6 = run(1, 1, False, keep=6)
+    sp = run(2, 7, True, span=110, keep=6)
+    np.testing.assert_array_equal(sp[0], ref[0])
+    np.testing.assert_array_equal(sp[1], ref[1])
+    for a, b in zip(sp[2], ref6[2]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(sp[3], ref[3]):
         np.testing.assert_array_equal(a, b)
     # (b) against the CPU oracle: batch 4 alone (its tap BN statistics are its own), first-step loss of the trajectory
     tr = otrain.DepthProbeTrainer(vsd, psd, max_step=100, warmup_step=10)
