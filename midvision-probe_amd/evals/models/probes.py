@@ -156,7 +156,9 @@ def make_conv(input_dim, hidden_dim, output_dim, num_layers, kernel_size=1):
 
 class MultiscaleHead(nn.Module):
     """Reference: probes.py:435-458 (DepthHead's / SurfaceNormalHead's default head_type).  kernel_size 1 (the default) runs on the
-    HIP path (mvp/multiscale.py); the reference's un-padded k > 1 variant shrinks every map and is not built."""
+    HIP path with the 1x1 convs commuted below the resamples (mvp/multiscale.py).  kernel_size > 1: the reference's convs carry no
+    padding (probes.py:400-412), so every conv shrinks its map by k - 1 and nothing commutes; the graph is evaluated as written, each
+    conv on the implicit-GEMM kernels (mvp.functional.conv2d_valid), the resamples on the resize kernel."""
 
     def __init__(self, input_dims, output_dim, hidden_dim=512, kernel_size=1, precision=None):
         super().__init__()
@@ -172,7 +174,7 @@ class MultiscaleHead(nn.Module):
         from mvp import multiscale as ms
 
         if self.kernel_size != 1:
-            raise NotImplementedError("MultiscaleHead with kernel_size > 1 (un-padded convs, probes.py:400-412) is not on the HIP path")
+            return self._forward_kxk(list(feats))
         feats = list(feats)
         h, w = feats[-1].shape[-2:]
         # bilinear resample to the last map's size (probes.py:449); it commutes with the 1x1 conv that precedes it in the reference
@@ -181,6 +183,26 @@ class MultiscaleHead(nn.Module):
         lq = ms.multiscale_logits(pack, self.input_dims, self, self.precision)
         K = self.conv_out[2].out_channels
         return lq[..., :K].permute(0, 3, 1, 2)
+
+
+def _multiscale_forward_kxk(self, feats):
+    """probes.py:447-458 as written (un-padded k x k convs).  The features are frozen (no gradient into them)."""
+    pr = self.precision
+    conv = lambda m, x, dx=True: MF.conv2d_valid(x, m.weight, m.bias, pr, need_input_grad=dx)  # noqa: E731
+    fs = [conv(self.convs[i], f.detach(), False) for i, f in enumerate(feats)]
+    h, w = fs[-1].shape[-2:]
+    fs = [f if tuple(f.shape[-2:]) == (h, w) else MF.interpolate(f, size=(h, w), mode="bilinear") for f in fs]
+    x = torch.cat(fs, dim=1).relu()
+    x = MF.interpolate(x, scale_factor=2, mode="bilinear")
+    x = conv(self.conv_mid[0], x).relu()
+    x = conv(self.conv_mid[2], x).relu()
+    x = conv(self.conv_mid[4], x).relu()
+    x = MF.interpolate(x, scale_factor=4, mode="bilinear")
+    x = conv(self.conv_out[0], x).relu()
+    return conv(self.conv_out[2], x)
+
+
+MultiscaleHead._forward_kxk = _multiscale_forward_kxk
 
 
 class DPT(nn.Module):

@@ -285,6 +285,70 @@ def linear_head_kxk(feats: Sequence[torch.Tensor], weight: torch.Tensor, bias: t
     return _LinearHeadKxK.apply(weight, bias, list(feats), precision)
 
 
+class _ConvValid(torch.autograd.Function):
+    """An UN-PADDED k x k convolution of an NCHW fp32 map (nn.Conv2d(cin, cout, k), what probes.py:400-412 ``make_conv`` builds), on the
+    implicit-GEMM kernels: the map is packed channels-last into a bf16 pair, Y = im2col(x) · Wᵀ + b (csrc/gemm.hip conv mode, pad 0);
+    backward: dW by the TN split-K kernel over pixels, dX = the "full" correlation of the output gradient with the flipped,
+    transposed taps (the same conv kernel at pad k-1), db a column sum.  Used by MultiscaleHead(kernel_size > 1)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, precision, need_dx):
+        from . import conv as cv
+
+        _need_cuda(x, "conv2d_valid")
+        B, C, H, W = x.shape
+        Cout, Cin, k, k2 = weight.shape
+        if Cin != C or k != k2 or H < k or W < k:
+            raise lib.MvpError(f"conv2d_valid: input {tuple(x.shape)} does not fit a {tuple(weight.shape)} kernel")
+        if C % 128:
+            raise lib.MvpError(f"conv2d_valid on the HIP path needs input channels % 128 == 0 (got {C})")
+        dev = x.device
+        tok = ops.empty_pair((B * H * W, C), precision, dev)
+        ops.pack_nchw_tokens(x.contiguous().float(), B, C, H * W, tok=tok, ld_tok=C, col_off=0)
+        g = cv.geom(B, H, W, C, k, k, 1, 0)
+        N4 = (Cout + 3) // 4 * 4
+        b4 = bias.detach().float().contiguous()
+        if N4 != Cout:
+            b4 = torch.cat([b4, b4.new_zeros(N4 - Cout)])
+        y = torch.empty(B, g["Ho"], g["Wo"], N4, dtype=torch.float32, device=dev)
+        cv.conv_gemm(tok, g, cv.pack_weight(weight, 0, precision, pad_cout_to=N4), N4, bias=b4, out_f32=y, precision=precision)
+        ctx.tok, ctx.g, ctx.cfg = tok, g, (Cout, N4, precision, bool(need_dx))
+        ctx.save_for_backward(weight)
+        return y[..., :Cout].permute(0, 3, 1, 2)  # NCHW view of the channels-last result
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import conv as cv
+
+        (weight,) = ctx.saved_tensors
+        Cout, N4, pr, need_dx = ctx.cfg
+        g = ctx.g
+        B, H, W, C, Ho, Wo, k = g["B"], g["H"], g["W"], g["C"], g["Ho"], g["Wo"], g["kh"]
+        dev = gy.device
+        M = B * Ho * Wo
+        gl = torch.zeros(M, N4, dtype=torch.float32, device=dev)
+        gl[:, :Cout] = gy.permute(0, 2, 3, 1).reshape(M, Cout)
+        LG = (N4 + 127) // 128 * 128
+        gP = cv.mask_split(gl, None, M, N4, ldo=LG, precision=pr)
+        dW = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        cv.conv_dw(gP, LG, ctx.tok, C, g, Cout, dW, precision=pr)
+        db = torch.empty(N4, dtype=torch.float32, device=dev)
+        ops.colsum(gl, db, M, N4)
+        dx = None
+        if need_dx:
+            wT = cv.pack_weight(weight, 1, pr, pad_cout_to=LG)  # [Cin, taps (flipped) x Cout]
+            dxc = torch.empty(B, H, W, C, dtype=torch.float32, device=dev)
+            cv.conv_gemm(gP, cv.geom(B, Ho, Wo, LG, k, k, 1, k - 1), wT, C, out_f32=dxc, precision=pr)
+            dx = dxc.permute(0, 3, 1, 2)
+        return dx, dW, db[:Cout].contiguous(), None, None
+
+
+def conv2d_valid(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, precision: int, need_input_grad: bool = True) -> torch.Tensor:
+    """``F.conv2d(x, weight, bias)`` (no padding, stride 1) for NCHW fp32 device maps, differentiable in weight, bias and (unless
+    ``need_input_grad`` is False: frozen features) the input."""
+    return _ConvValid.apply(x, weight, bias, precision, need_input_grad)
+
+
 # --------------------------------------------------------------------------- depth predictors
 class _DepthPredict(torch.autograd.Function):
     @staticmethod

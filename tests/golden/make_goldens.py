@@ -217,6 +217,18 @@ def golden_probes_multiscale(pr):
         for n, gr in _grads(probe).items():
             out[f"{name}__grad__{n}"] = gr
         print("probe", name, tuple(y.shape), probe.name)
+    # kernel_size 3: make_conv builds UN-PADDED convs (probes.py:400-412), every conv shrinks its map by 2
+    k3_feats = [torch.randn(B, C, 6, 7, generator=g) for _ in range(4)]
+    out["k3_feats"] = np.stack([_np(f) for f in k3_feats])
+    probe = pr.DepthHead(feat_dim=[C] * 4, head_type="multiscale", hidden_dim=16, kernel_size=3, prediction_type="sigdepth")
+    probe.load_state_dict(oprobes.make_multiscale_weights([C] * 4, 1, hidden=16, k=3, seed=23), strict=True)
+    y = probe([f.clone() for f in k3_feats])
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(31))
+    (y * gy).sum().backward()
+    out["depth_ms_k3__out"], out["depth_ms_k3__gy"], out["depth_ms_k3__name"] = _np(y), _np(gy), np.array(probe.name)
+    for n, gr in _grads(probe).items():
+        out[f"depth_ms_k3__grad__{n}"] = gr
+    print("probe depth_ms_k3", tuple(y.shape), probe.name)
     np.savez_compressed(os.path.join(OUT, "probes_multiscale.npz"), **out)
 
 

@@ -132,6 +132,39 @@ def test_multiscale_head_vs_oracle(dev, kind):
         assert 1 - float(a64 @ b64 / (a64.norm() * b64.norm())) < 1e-3, (kind, n)
 
 
+@pytest.mark.parametrize("kind", ["depth_bins", "snorm_ua"])
+def test_multiscale_head_k3_vs_oracle(dev, kind):
+    """MultiscaleHead(kernel_size=3) (probes.py:435-458 with make_conv's un-padded 3x3 convs, :400-412): forward + all parameter
+    gradients vs the oracle (pinned to the reference module for k = 3 by tests/golden/probes_multiscale.npz ``depth_ms_k3``).
+    7x8 maps -> 5x6 -> x2 -> three convs -> 4x6 -> x4 -> two convs -> 12x20."""
+    from evals.models.probes import DepthHead, SurfaceNormalHead
+    from oracle import probes as oprobes
+
+    g = torch.Generator().manual_seed(6)
+    B, Hd, dims = 2, 128, [128] * 4
+    feats = [torch.randn(B, 128, 7, 8, generator=g) for _ in range(4)]
+    if kind == "snorm_ua":
+        probe, odim = SurfaceNormalHead(feat_dim=dims, head_type="multiscale", uncertainty_aware=True, hidden_dim=Hd, kernel_size=3), 4
+    else:
+        probe, odim = DepthHead(feat_dim=dims, head_type="multiscale", prediction_type="bindepth", hidden_dim=Hd, kernel_size=3), 256
+    sd = oprobes.make_multiscale_weights(dims, odim, hidden=Hd, k=3, seed=10)
+    probe.load_state_dict(sd, strict=True)
+    probe = probe.to(dev)
+    y = probe([f.to(dev) for f in feats])
+    sd_r = {n: t.clone().requires_grad_(True) for n, t in sd.items()}
+    y_ref = oprobes.snorm_head(sd_r, feats, "multiscale", 3) if kind == "snorm_ua" else oprobes.depth_head(sd_r, feats, "multiscale", 3, "bindepth")
+    assert tuple(y.shape) == tuple(y_ref.shape) and tuple(y.shape[-2:]) == (12, 20)
+    gy = torch.randn(y_ref.shape, generator=g)
+    (y_ref * gy).sum().backward()
+    (y * gy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_l2(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 1e-4, kind
+    for n, p in probe.named_parameters():
+        a64, b64 = p.grad.double().cpu().flatten(), sd_r[n].grad.double().flatten()
+        assert float((a64 - b64).norm() / b64.norm()) < 3e-2, (kind, n)            # ReLU-gate flips near 0 (DESIGN §2)
+        assert 1 - float(a64 @ b64 / (a64.norm() * b64.norm())) < 1e-3, (kind, n)
+
+
 def test_dino_return_cls(dev):
     """dino.py:206-207: single tap + return_cls -> embeds[0][:, 0] (tap-BN normalised when add_norm)."""
     from evals.models.dino import DINO

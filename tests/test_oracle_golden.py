@@ -144,6 +144,20 @@ def test_multiscale_head_fwd_bwd(name, kind, src, odim):
         assert rel_l2(t.grad.numpy(), g[f"{name}__grad__{n}"]) < 2e-4, n
 
 
+def test_multiscale_head_k3_fwd_bwd():
+    """MultiscaleHead(kernel_size=3): un-padded convs (probes.py:400-412), every conv shrinks its map by 2 — 6x7 maps end as a 4x12
+    depth map — vs outputs + grads of the reference module."""
+    g = load_golden("probes_multiscale.npz")
+    feats = [T(g["k3_feats"][i]) for i in range(4)]
+    sd = {n: t.requires_grad_(True) for n, t in oprobes.make_multiscale_weights([24] * 4, 1, hidden=16, k=3, seed=23).items()}
+    y = oprobes.depth_head(sd, feats, "multiscale", 3, "sigdepth")
+    assert str(g["depth_ms_k3__name"]) == "sigdepth_multiscale_k3" and tuple(y.shape) == (2, 1, 4, 12)
+    assert rel_l2(y.detach().numpy(), g["depth_ms_k3__out"]) < TOL
+    (y * T(g["depth_ms_k3__gy"])).sum().backward()
+    for n, t in sd.items():
+        assert rel_l2(t.grad.numpy(), g[f"depth_ms_k3__grad__{n}"]) < 2e-4, n
+
+
 # ------------------------------------------------------------------ losses
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 16])
 def test_depth_loss(B):
