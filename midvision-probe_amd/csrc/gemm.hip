@@ -434,11 +434,18 @@ extern "C" int mvp_gemm_streamk(const mvp_gemm_args* a, void* stream);  // gemm_
 // prologue + epilogue per round, so: long K from 128 tiles on, short K from 200 tiles on when the rounds are >= 80 % full.
 // MVP_GEMM_PP = 0 / 1 (diagnostic override): never / whenever the kernel supports the arguments.
 static bool pp_takes(const mvp_gemm_args* a) {
-  if (a->precision != MVP_PREC_BF16X3 || a->conv || a->splitk > 1 || (a->K & 31) || a->K < 64) return false;
+  if (a->precision != MVP_PREC_BF16X3 || a->splitk > 1 || (a->K & 31) || a->K < 64) return false;
+  static const int env = [] { const char* e = getenv("MVP_GEMM_PP"); return e ? atoi(e) : -1; }();
+  if (a->conv) {
+    // convolutions (the DPT probe's 3x3 layers at 8x the token grid: M = 200 704 pixels, K = 4608 / 2304): the large-M kernel with
+    // the im2col staging, its fused masks / residuals through the generic epilogue; from two full rounds of 256x256 tiles on
+    if (a->pair_layout != MVP_PAIR_SEPARATE || (a->tile_policy & MVP_TILES_NO_PP) || (a->cC & 31) || a->K < 1024 || a->residual_hi) return false;
+    if (env >= 0) return env != 0;
+    return (long)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 512;
+  }
   if (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) return false;
   if (a->pair_layout != MVP_PAIR_SEPARATE) return true;  // only that kernel reads the interleaved layout
   if (a->tile_policy & MVP_TILES_NO_PP) return false;
-  static const int env = [] { const char* e = getenv("MVP_GEMM_PP"); return e ? atoi(e) : -1; }();
   if (env >= 0) return env != 0;
   if (a->N <= 256 && a->K >= 2048) return false;  // the probe head: few tiles, split-K
   const long t = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);

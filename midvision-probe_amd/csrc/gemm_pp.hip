@@ -64,8 +64,11 @@ constexpr int PP_TILE_B = 256 * 128;     // bytes per operand tile per k-step (h
 constexpr int PP_BUF_B = 2 * PP_TILE_B;  // A tile + W tile of one k-step
 constexpr int PP_SMEM = 2 * PP_BUF_B;    // two k-step buffers = 128 KiB
 
-template <bool ILVA, bool ILVW, bool EXT>
+// CONV (separate hi / lo arrays only): the A operand is the implicit im2col of a channels-last activation, exactly gemm.hip's conv mode
+// (K index = tap * C + c, a 32-deep k-step never straddles a tap: C % 32 == 0; padding taps are read as buffer-out-of-range zeros).
+template <bool ILVA, bool ILVW, bool EXT, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
+  static_assert(!(CONV && ILVA), "the convolution reads separate hi / lo activation arrays");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MT = 8, NT = 4;
 #if MVP_PP_STAMP
@@ -102,18 +105,29 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   auto piece_row0 = [&](bool ilv, int q) { return ilv ? q * 8 : (q & 15) * 16; };  // first tile row of piece q
   auto piece_lo = [&](bool ilv, int q) { return ilv ? 0 : (q >> 4); };             // 1: the piece belongs to the lo array (separate arrays)
 
-  const size_t a_base = (size_t)m0 * p.lda, w_base = (size_t)n0 * p.ldw;
+  const size_t a_base = CONV ? 0 : (size_t)m0 * p.lda, w_base = (size_t)n0 * p.ldw;
+  const int cHs = CONV ? (p.cH >> p.cup) : 0, cWs = CONV ? (p.cW >> p.cup) : 0;
+  // (conv) the resource covers exactly the activation: an offset past it — what a padding tap gets — reads as zeros
+  const unsigned a_bytes = CONV ? (unsigned)min((size_t)0x7fffff00u, ((size_t)(p.M / (p.cHo * p.cWo)) * cHs * cWs * p.lda) * 2) : 0x7fffff00u;
   const mvp_bf16* const pa_hi = p.a_hi + a_base;
   const mvp_bf16* const pa_lo = (ILVA ? p.a_hi : p.a_lo) + a_base;
   const mvp_bf16* const pw_hi = p.w_hi + w_base;
   const mvp_bf16* const pw_lo = (ILVW ? p.w_hi : p.w_lo) + w_base;
   int a_voff[4], w_voff[4];  // per-lane byte offsets of this wave's pieces: [HA0 e0, HA0 e1, HA1 e0, HA1 e1], [HB 0..3]
+  int cv_img[4], cv_yx[4];  // (conv) per piece row: byte offset of its image, top-left input coordinates (y << 16 | x, biased by 0x4000)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = qa[e & 1] + (e >> 1) * HALF_STEP;
     const int row = min(piece_row0(ILVA, q) + prow_of(ILVA), p.M - 1 - m0);  // rows past M re-read the last row (never stored)
     a_voff[e] = row * p.lda * 2 + csrc_of(ILVA);
+    if (CONV) {
+      const int m = m0 + row;
+      const int x = m % p.cWo, t = m / p.cWo;
+      cv_img[e] = (t / p.cHo) * cHs * cWs * p.lda * 2 + csrc_of(false);
+      cv_yx[e] = (((t % p.cHo) * p.cstride - p.cpad + 0x4000) << 16) | (x * p.cstride - p.cpad + 0x4000);
+    }
   }
+  int ct_ky[2] = {0, 0}, ct_kx[2] = {0, 0}, ct_c0[2] = {0, 0};  // (conv) tap and channel of the NEXT k-step each half stages (k ascending per half)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int q = 4 * wave + e;
@@ -126,9 +140,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int q = qa[e] + half * HALF_STEP;
-      lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, 0x7fffff00u, smem + par * PP_BUF_B + q * 1024, a_voff[half * 2 + e], kt * KSTEP_A);
+      if (CONV) {
+        const int yy = (cv_yx[half * 2 + e] >> 16) - 0x4000 + ct_ky[half], xx = (cv_yx[half * 2 + e] & 0xffff) - 0x4000 + ct_kx[half];
+        const bool ok = ((unsigned)yy < (unsigned)p.cH) && ((unsigned)xx < (unsigned)p.cW);
+        const int off = cv_img[half * 2 + e] + (((yy >> p.cup) * cWs + (xx >> p.cup)) * p.lda + ct_c0[half]) * 2;
+        lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, a_bytes, smem + par * PP_BUF_B + q * 1024, ok ? off : 0x7fffff80, 0);
+      } else {
+        lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, 0x7fffff00u, smem + par * PP_BUF_B + q * 1024, a_voff[half * 2 + e], kt * KSTEP_A);
+      }
     }
 #endif
+    if (CONV) {  // every half is staged in increasing k order: advance its running tap position
+      ct_c0[half] += 32;
+      if (ct_c0[half] >= p.cC) {
+        ct_c0[half] = 0;
+        if (++ct_kx[half] == p.ckw) { ct_kx[half] = 0; ++ct_ky[half]; }
+      }
+    }
   };
   auto stage_w = [&](int par, int kt) {  // this wave's four pieces of HB of k-step kt
 #if MVP_PP_ABLATE != 2
@@ -323,20 +351,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #endif
 }
 
-template <bool ILVA, bool ILVW>
+template <bool ILVA, bool ILVW, bool CONV = false>
 int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
   static int configured = [] {
-    int e = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
-    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+    int e = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, false, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+    if (e == 0) e = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, true, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
     return e;
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
   const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi;
   if (ext)
-    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true, CONV>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, false>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, false, CONV>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
@@ -348,13 +376,20 @@ extern "C" int mvp_gemm_pp(const mvp_gemm_args* a, void* stream) {
   if (a->pair_layout < 0 || a->pair_layout > (MVP_PAIR_A_ILV32 | MVP_PAIR_W_ILV32)) return MVP_EINVAL;
   const bool ilva = a->pair_layout & MVP_PAIR_A_ILV32, ilvw = a->pair_layout & MVP_PAIR_W_ILV32;
   if ((!ilva && !a->a_lo) || (!ilvw && !a->w_lo)) return MVP_EINVAL;
-  if (a->M <= 0 || a->N <= 0 || a->K < 64 || (a->K & 31) || a->conv || a->splitk > 1) return MVP_EINVAL;
+  if (a->M <= 0 || a->N <= 0 || a->K < 64 || (a->K & 31) || a->splitk > 1) return MVP_EINVAL;
+  if (a->conv) {  // gemm.hip's conv contract (mvp_gemm_bias_act_res validates the same)
+    if (ilva || a->cC <= 0 || (a->cC & 31) || a->ckh <= 0 || a->ckw <= 0 || a->cstride <= 0 || a->cpad < 0 || a->cup < 0) return MVP_EINVAL;
+    if (a->K != a->ckh * a->ckw * a->cC || a->cHo <= 0 || a->cWo <= 0 || (a->M % (a->cHo * a->cWo))) return MVP_EINVAL;
+    if ((a->cH & ((1 << a->cup) - 1)) || (a->cW & ((1 << a->cup) - 1)) || a->cH >= 0x4000 || a->cW >= 0x4000 || a->cpad >= 0x2000) return MVP_EINVAL;
+    if ((int64_t)(a->M / (a->cHo * a->cWo)) * (a->cH >> a->cup) * (a->cW >> a->cup) * a->lda * 2 >= 0x7fffff00ll) return MVP_EINVAL;
+  }
   if ((a->lda & 7) || (a->ldw & 7) || a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   if (a->out_pair_layout != MVP_PAIR_SEPARATE && (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31))) return MVP_EINVAL;
   // 32-bit per-lane byte offsets: 256 tile rows of the widest supported row must stay below 2 GiB
   if ((int64_t)256 * a->lda * 2 >= 0x7fffff00ll || (int64_t)256 * a->ldw * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (a->conv) return ilvw ? launch_pp<false, true, true>(a, st) : launch_pp<false, false, true>(a, st);
   if (ilva) return ilvw ? launch_pp<true, true>(a, st) : launch_pp<true, false>(a, st);
   return ilvw ? launch_pp<false, true>(a, st) : launch_pp<false, false>(a, st);
 }

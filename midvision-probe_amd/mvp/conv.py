@@ -48,8 +48,11 @@ def pack_weight(w: torch.Tensor, mode: int, precision: int, pad_cout_to: int = 0
 
 
 def conv_gemm(x: Pair, g: dict, wk: Pair, N: int, *, bias=None, act=lib.ACT_NONE, residual=None, residual2=None, out_f32=None,
-              out: Optional[Pair] = None, out_mask=None, relu_mask=None, mask_mode=0, precision=PREC_BF16X3, ldo=None, lda=None, act_after_res=False) -> None:
-    """Implicit-GEMM convolution: Y[B*Ho*Wo, N] = act(im2col(x) · wkᵀ + bias) (+ residual (+ residual2))."""
+              out: Optional[Pair] = None, out_mask=None, relu_mask=None, mask_mode=0, precision=PREC_BF16X3, ldo=None, lda=None, act_after_res=False,
+              tile_policy: int = 0) -> None:
+    """Implicit-GEMM convolution: Y[B*Ho*Wo, N] = act(im2col(x) · wkᵀ + bias) (+ residual (+ residual2)).  From two rounds of 256x256
+    tiles on (the DPT probe's layers at 8x the token grid) the library runs it on the large-M ping-pong kernel (csrc/gemm_pp.hip,
+    CONV mode; ``tile_policy`` = lib.TILES_NO_PP keeps the tile kernels: tests compare the two bit for bit)."""
     M = g["B"] * g["Ho"] * g["Wo"]
     K = g["kh"] * g["kw"] * g["C"]
     o_hi, o_lo = out if out is not None else (None, None)
@@ -59,6 +62,7 @@ def conv_gemm(x: Pair, g: dict, wk: Pair, N: int, *, bias=None, act=lib.ACT_NONE
         lib.ptr(o_hi), lib.ptr(o_lo), M, N, K, lda if lda is not None else g["C"], K, ldn, ldn, ldn, act, precision, 0, 0, 0, 0,
         1, g["H"], g["W"], g["C"], g["Ho"], g["Wo"], g["kh"], g["kw"], g["stride"], g["pad"], g["up"], lib.ptr(zero_page(x[0].device)),
         lib.ptr(relu_mask), lib.ptr(out_mask), ldn, mask_mode, lib.ptr(residual2), int(act_after_res))
+    args.tile_policy = int(tile_policy)
     lib.call("mvp_gemm_bias_act_res", args)
 
 

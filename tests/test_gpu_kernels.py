@@ -504,3 +504,58 @@ def test_layernorm_and_attention_interleaved_outputs_match_separate(dev):
         ops.attention(qkv, ilv, B, N, H, 0.125, lib.PREC_BF16X3)
         torch.cuda.synchronize()
         assert torch.equal(ilv.separate()[0], sep[0]) and torch.equal(ilv.separate()[1], sep[1]), (B, N)
+
+
+@pytest.mark.parametrize("case", ["fwd_relu_mask", "dgrad_gate", "residuals", "upsampled_input"])
+def test_conv_on_the_large_m_kernel_equals_the_tile_kernels(dev, case):
+    """3x3 convolutions big enough for the large-M ping-pong kernel (csrc/gemm_pp.hip CONV mode: >= 512 tiles of 256x256, K >= 1024 —
+    the DPT probe's layers at 8x the token grid, probes.py:384-398) against the 128x128 tile kernels (``tile_policy`` TILES_NO_PP),
+    which the DPT tests hold to the oracle: same k order, same epilogue, so bit-identical — with the fused epilogues the DPT forward /
+    backward use (ReLU + gate mask out, gated by a stored mask, two residuals, a virtually 2x-upsampled input) — plus a spot check of
+    output pixels against a direct fp64 evaluation."""
+    from mvp import conv as cv, lib, ops
+
+    g = torch.Generator().manual_seed(42)
+    B, H, W, C, N = 2, 192, 192, 128, 512
+    up = 1 if case == "upsampled_input" else 0
+    Hs, Ws = H >> up, W >> up
+    x = torch.randn(B * Hs * Ws, C, generator=g).to(dev)
+    w = (torch.randn(N, C, 3, 3, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    xP = ops.split_bf16(x, 3)
+    geo = cv.geom(B, H, W, C, 3, 3, 1, 1, up=up)
+    M = B * H * W
+    wk = cv.pack_weight(w, 0, 3)
+    kw = dict(bias=bias, precision=3)
+    if case == "fwd_relu_mask":
+        kw.update(act=lib.ACT_RELU)
+    elif case == "dgrad_gate":
+        kw.update(relu_mask=(torch.rand(M, N, generator=g) > 0.4).to(torch.uint8).to(dev), mask_mode=2)
+    elif case == "residuals":
+        kw.update(act=lib.ACT_RELU, residual=torch.randn(M, N, generator=g).to(dev), residual2=torch.randn(M, N, generator=g).to(dev))
+
+    def run(policy):
+        o32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        oP = ops.empty_pair((M, N), 3, dev)
+        om = torch.zeros(M, N, dtype=torch.uint8, device=dev) if case == "fwd_relu_mask" else None
+        cv.conv_gemm(xP, geo, wk, N, out_f32=o32, out=oP, out_mask=om, tile_policy=policy, **kw)
+        return o32, oP, om
+
+    a = run(0)
+    b = run(lib.TILES_NO_PP)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1][0], b[1][0]) and torch.equal(a[1][1], b[1][1])
+    if a[2] is not None:
+        assert torch.equal(a[2], b[2])
+    if case == "fwd_relu_mask":  # direct fp64 evaluation of a few pixels (borders included)
+        x4 = x.double().view(B, Hs, Ws, C)
+        for (bi, y, xx) in [(0, 0, 0), (1, H - 1, W - 1), (0, 17, 0), (1, 100, 57)]:
+            acc = bias.double().clone()
+            for ky in range(3):
+                for kx in range(3):
+                    yy, xc = y + ky - 1, xx + kx - 1
+                    if 0 <= yy < H and 0 <= xc < W:
+                        acc += w[:, :, ky, kx].double() @ x4[bi, yy >> up, xc >> up]
+            ref = acc.clamp_min(0)
+            got = a[0][(bi * H + y) * W + xx].double()
+            assert float((got - ref).abs().max()) < 2e-4 * float(ref.abs().max() + 1)
