@@ -311,8 +311,9 @@ def main():
 
     # forwards in flight: --inflight (None = the trainers' default: mvp.pipeline.default_depth / default_group), --group batches per forward
     d0 = default_depth(probe)
-    pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else (d0 if (d0 == 1 or os.environ.get("MVP_INFLIGHT") is not None) else None),
-                           group=args.group, span=args.span)
+    d_final = os.environ.get("MVP_INFLIGHT") is not None or os.environ.get("MVP_FORCE_DEVICE") is not None
+    pipe = FeaturePipeline(model, args.inflight if args.inflight is not None else (d0 if d_final else None),
+                           group=args.group, span=args.span, ungrouped_depth=d0 if args.inflight is None else None)
     pipe.resolve_group(batches[0][0])
     if args.pmc_child:
         args.warmup, args.steps = pipe.group, ((2 * pipe.span) // B if pipe.span else 2 * pipe.group)  # about two full forwards of the timed run's shape

@@ -200,6 +200,167 @@ __global__ __launch_bounds__(256) void dl_grad_kernel(const mvp_depth_loss_args 
   }
 }
 
+// ----------------------------------------------------------------------------- DepthLoss in two launches (B <= 16)
+// The four-kernel form above passes the log-differences through HBM (a [B*HW] scratch array written once and read by two kernels)
+// and strings three dependent launches before the gradient: ~36 B per element and four launch latencies for an algorithmic 12 B.
+// For B <= 16 (the reference's batch size and every configuration of BASELINE.json) a thread keeps the B log-differences of ONE pixel
+// in registers, so (1) one pass over pred / target yields every sum the loss needs — s1, s2, the per-image valid counts and the four
+// pair sums — and (2) the gradient pass re-derives the log-differences from the same two arrays (2B logf per pixel, cheap next to
+// the loads) after every block has reduced the partials itself (fixed order: same scalars in every block, no finalize launch).
+// 20 B per element, two launches.  Arithmetic per term as above (fp32 log-differences, fp64 sums, Q1 pairs, Q2 zeroing).
+constexpr int DLF_NB = 512;  // blocks (pixel chunks) at most
+
+struct DLFWs {
+  double* part;  // [DLF_NB][6]: s1, s2, pair sums of strides 1, 2, 4, 6
+  int* cnt;      // [DLF_NB][16]: valid pixels per image
+};
+
+__device__ __host__ inline DLFWs dlf_ws(void* ws, int B, int64_t HW) {
+  const DLWs w = dl_ws(ws, B, HW);
+  DLFWs f;
+  f.part = w.scal + DL_SCAL;
+  f.cnt = (int*)(f.part + DLF_NB * 6);
+  return f;
+}
+
+template <bool WRITE_TARGET>
+__device__ __forceinline__ void dlf_pixel(const mvp_depth_loss_args& p, int64_t i, float (&g)[16], bool (&ok)[16], float (&pr)[16]) {
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int64_t o = (int64_t)min(b, p.B - 1) * p.HW + i;
+    float t = p.target[o];
+    pr[b] = p.pred[o];
+    if (WRITE_TARGET && b < p.B && t > p.max_depth) p.target[o] = 0.f;  // Q2: zeroed in place
+    if (t > p.max_depth) t = 0.f;
+    ok[b] = (b < p.B) && (t > 0.f);
+    g[b] = ok[b] ? logf(pr[b] + p.eps) - logf(t + p.eps) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void dlf_stats_kernel(const mvp_depth_loss_args p) {
+  __shared__ double red[4];
+  __shared__ int scnt[16];
+  const DLFWs w = dlf_ws(p.workspace, p.B, p.HW);
+  const int64_t per = (p.HW + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = blockIdx.x * per, i1 = min(p.HW, i0 + per);
+  if (threadIdx.x < 16) scnt[threadIdx.x] = 0;
+  double s1 = 0.0, s2 = 0.0, acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int cnt[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) cnt[b] = 0;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    float g[16], pr[16];
+    bool ok[16];
+    dlf_pixel<true>(p, i, g, ok, pr);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      s1 += (double)g[b];
+      s2 += (double)g[b] * (double)g[b];
+      cnt[b] += ok[b] ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int s = dl_stride(k);
+      float a = 0.f;
+#pragma unroll
+      for (int b1 = 0; b1 + 2 * s < 16; b1 += s)
+        if (ok[b1] && ok[b1 + 2 * s]) a += fabsf(g[b1] - g[b1 + 2 * s]);
+      acc[k] += (double)a;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    int c = cnt[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&scnt[b], c);  // integers: exact in any order
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = block_sum(acc[k], red);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* o = w.part + (int64_t)blockIdx.x * 6;
+    o[0] = s1; o[1] = s2; o[2] = acc[0]; o[3] = acc[1]; o[4] = acc[2]; o[5] = acc[3];
+  }
+  if (threadIdx.x < 16) w.cnt[blockIdx.x * 16 + threadIdx.x] = scnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void dlf_grad_kernel(const mvp_depth_loss_args p, const int nb) {
+  __shared__ double red[4];
+  __shared__ int scnt[16];
+  __shared__ float coef[8];
+  const DLFWs w = dlf_ws(p.workspace, p.B, p.HW);
+  // every block reduces the nb partial rows itself, in the same fixed order: identical scalars everywhere, no finalize launch
+  if (threadIdx.x < 16) scnt[threadIdx.x] = 0;
+  __syncthreads();
+  double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  int c16 = 0;
+  for (int r = threadIdx.x; r < nb; r += 256) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] += w.part[(int64_t)r * 6 + k];
+  }
+  for (int e = threadIdx.x; e < nb * 16; e += 256) {  // e % 16 is the same image for every e of a thread (256 % 16 == 0)
+    c16 += w.cnt[e];
+  }
+  if (c16) atomicAdd(&scnt[threadIdx.x & 15], c16);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = block_sum(v[k], red);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double n = 0.0;
+    for (int b = 0; b < p.B; ++b) n += (double)scnt[b];
+    const double mean = v[0] / n;
+    const double ls = sqrt(v[1] / n - (double)p.sigma * mean * mean);
+    double lg = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      const int s = dl_stride(k);
+      double ns = 0.0;
+      for (int b = 0; b < p.B; b += s) ns += (double)scnt[b];
+      lg += v[2 + k] / ns;  // 0/0 -> NaN exactly like the reference when a sub-batch has no valid pixel
+      coef[2 + k] = (float)((double)p.w_grad / ns);
+    }
+    coef[0] = (float)((double)p.w_sig / (ls * n));                             // coefficient of g
+    coef[1] = (float)((double)p.w_sig * (double)p.sigma * v[0] / (ls * n * n));  // constant term
+    if (blockIdx.x == 0) {
+      p.loss[0] = (float)((double)p.w_sig * ls + (double)p.w_grad * lg);
+      p.loss[1] = (float)ls;
+      p.loss[2] = (float)lg;
+    }
+  }
+  __syncthreads();
+  if (!p.grad_pred) return;
+  const float c1 = coef[0], c2 = coef[1];
+  const float invn[4] = {coef[2], coef[3], coef[4], coef[5]};
+  const int64_t per = (p.HW + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = blockIdx.x * per, i1 = min(p.HW, i0 + per);
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    float g[16], pr[16];
+    bool ok[16];
+    dlf_pixel<false>(p, i, g, ok, pr);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      float out = 0.f;
+      if (ok[b]) {
+        float acc = c1 * g[b] - c2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int s = dl_stride(k);
+          if (b % s) continue;
+          float sg = 0.f;
+          if (b - 2 * s >= 0 && ok[(b - 2 * s) & 15]) { const float d = g[b] - g[(b - 2 * s) & 15]; sg += (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
+          if (b + 2 * s < 16 && ok[(b + 2 * s) & 15]) { const float d = g[b] - g[(b + 2 * s) & 15]; sg += (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f); }
+          acc += invn[k] * sg;
+        }
+        out = acc / (pr[b] + p.eps);
+      }
+      if (b < p.B) p.grad_pred[(int64_t)b * p.HW + i] = out;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- angular loss
 constexpr int AL_NB = 128;
 
@@ -291,7 +452,7 @@ inline int grid_for(int64_t work) {
 
 extern "C" int64_t mvp_depth_loss_workspace_bytes(int B, int64_t HW) {
   const int64_t ld = ((int64_t)B * HW * 4 + 15) & ~(int64_t)15;
-  return ld + ((int64_t)B * DL_NCH * 3 + DL_NCH2 * 4 + DL_SCAL) * 8;
+  return ld + ((int64_t)B * DL_NCH * 3 + DL_NCH2 * 4 + DL_SCAL) * 8 + (int64_t)DLF_NB * (6 * 8 + 16 * 4);
 }
 
 extern "C" int mvp_depth_loss_fwd_bwd(const mvp_depth_loss_args* a, void* stream) {
@@ -299,6 +460,14 @@ extern "C" int mvp_depth_loss_fwd_bwd(const mvp_depth_loss_args* a, void* stream
   if (a->B <= 0 || a->B > 1024 || a->HW <= 0) return MVP_EINVAL;
   if (a->workspace_bytes < mvp_depth_loss_workspace_bytes(a->B, a->HW)) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  static const bool fused_ok = [] { const char* e = getenv("MVP_DEPTH_LOSS_FUSED"); return !e || atoi(e) != 0; }();
+  if (a->B <= 16 && fused_ok) {  // two launches, log-differences in registers
+    const int nb = (int)max((int64_t)1, min((int64_t)DLF_NB, (a->HW + 255) / 256));
+    hipLaunchKernelGGL(dlf_stats_kernel, dim3(nb), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(dlf_grad_kernel, dim3(a->grad_pred ? nb : 1), dim3(256), 0, s, *a, nb);
+    MVP_LAUNCH_CHECK();
+    return MVP_OK;
+  }
   hipLaunchKernelGGL(dl_stats_kernel, dim3(DL_NCH, a->B), dim3(256), 0, s, *a);
   hipLaunchKernelGGL(dl_pairs_kernel, dim3(DL_NCH2), dim3(256), 0, s, *a);
   hipLaunchKernelGGL(dl_finalize_kernel, dim3(1), dim3(256), 0, s, *a);

@@ -336,7 +336,7 @@ def depth_loss(pred, target, loss, grad_pred, workspace, B, HW, w_sig=10.0, w_gr
     a = lib.DepthLossArgs(lib.ptr(pred), lib.ptr(target), lib.ptr(loss), lib.ptr(grad_pred), lib.ptr(workspace),
                           workspace.numel() * workspace.element_size(), B, HW, w_sig, w_grad, max_depth, eps, sigma)
     # algorithmic HBM bytes: pred + target read, gradient written (one pass each)
-    _traced("hbm", "depth_loss (dl_stats+dl_pairs+dl_finalize+dl_grad)", 0, float(B * HW * 12), lambda: lib.call("mvp_depth_loss_fwd_bwd", a))
+    _traced("hbm", "depth_loss (dlf_stats+dlf_grad)" if B <= 16 else "depth_loss (dl_stats+dl_pairs+dl_finalize+dl_grad)", 0, float(B * HW * 12), lambda: lib.call("mvp_depth_loss_fwd_bwd", a))
 
 
 def angular_loss(pred, gt, mask_u8, loss, grad_pred, workspace, B, Cp, HW, eps=1e-4) -> None:

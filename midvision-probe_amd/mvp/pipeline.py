@@ -141,7 +141,8 @@ def shared_tiles(on: bool = True):
 
 def default_depth(probe=None, group: int = 1) -> int:
     """Forwards submitted ahead of the probe step (= buffer slots) in the trainers and bench.py.  They run on min(depth, 3) side
-    streams.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).  Otherwise: 1 under a DPT probe; 2 for grouped
+    streams.  MVP_INFLIGHT wins when set (1 = everything on the trainer's stream).  Otherwise: 1 under a DPT probe whose forwards are
+    single batches (``FeaturePipeline(ungrouped_depth=...)``: grouped ones do run beside it); 2 for grouped
     forwards (``group`` > 1: one group is being consumed batch by batch while the next one's forward runs); 4 single-batch forwards.
     Measured on MI355X at B=16 (bench.py, img/s), single-batch forwards: linear probe at 224^2 — one chain 5440-5660; two chains
     6380-6450; three chains 6610 with the same tiles and 7150-7340 with the shared-chip tiles (tile_policy); four chains 6210-6340, five
@@ -250,7 +251,8 @@ class FeaturePipeline:
     that no capture falls into the run); a ragged last group runs eagerly.
     A graph is tied to the engine it was captured from (rebuilt weights invalidate it: new key, new capture)."""
 
-    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None, group: int = 1, span: int = None):
+    def __init__(self, model, depth: int = None, run_ahead: int = None, graphs: bool = None, streams: int = None, group: int = 1, span: int = None,
+                 ungrouped_depth: int = None):
         """``run_ahead``: the host may be at most this many forwards ahead of the device (MVP_RUN_AHEAD, default 8; 0 = unbounded).
         The reference's loop syncs every step (``loss.item()``, train_depth.py:143); a loop that never syncs would otherwise queue
         hundreds of launches (and keep their argument buffers alive).  Throughput-neutral on MI355X (tools/micro/pipeline_probe.py,
@@ -267,6 +269,9 @@ class FeaturePipeline:
             self.group = 1
         # images per span forward (module docstring, "Spans"): None = default_span when ``group`` is chosen automatically, else off
         self._span_arg = span
+        # depth to fall to when ``depth`` is None and the forwards turn out to be single batches (``default_depth(probe)``: a DPT probe
+        # step gains from grouped forwards beside it, 762 -> 802 img/s, but loses to single-batch ones, 739-748 -> 699-723)
+        self._ungrouped_depth = ungrouped_depth
         self.span, self.span_batch, self._span_resolved = 0, 0, False
         # (stream priorities do not help: the device offers only (0, -1), and high-priority side streams measured the same)
         # ``depth`` forwards are submitted ahead (one buffer slot each); they run on ``streams`` side streams = kernel chains side by side
@@ -330,6 +335,10 @@ class FeaturePipeline:
             # one stream 8357 / 8706, two 8326 / 8714), and one chain keeps every per-kernel measurement in the regime of the timed run
             self.chains = max(1, min(self.depth, self._streams_arg if self._streams_given else 1))
             self.streams = self.streams[:self.chains]
+        elif auto and depth_free and self._ungrouped_depth is not None and self._ungrouped_depth < self.depth:
+            self.depth = max(1, int(self._ungrouped_depth))
+            self.chains = max(1, min(self.depth, self.chains))
+            self.streams = self.streams[:self.chains] if self.depth > 1 else []
         return self.group
 
     # ------------------------------------------------------------------ one forward on a slot's stream
@@ -562,12 +571,13 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
     ``default_group``; an epoch's ragged last batch and whatever is left over run as smaller forwards).  ``pipe``: an existing
     pipeline to reuse (its captured graphs); it must be empty."""
     if pipe is None:
+        hint = None
         if depth is None:
-            d = default_depth(probe)
-            # 1 (DPT probe, ranks rehearsing on one card, MVP_INFLIGHT=1) is final; otherwise the pipeline picks its own default once it
-            # knows whether the forwards are grouped (2 slots) or single batches (4)
-            depth = d if (d == 1 or os.environ.get("MVP_INFLIGHT") is not None) else None
-        pipe = FeaturePipeline(model, depth, group=group)
+            hint = default_depth(probe)
+            # MVP_INFLIGHT and ranks rehearsing on one card are final; otherwise the pipeline picks its own default once it knows
+            # whether the forwards are grouped (2 slots, DPT probe included) or single batches (4; 1 under a DPT probe)
+            depth = hint if (os.environ.get("MVP_INFLIGHT") is not None or os.environ.get("MVP_FORCE_DEVICE") is not None) else None
+        pipe = FeaturePipeline(model, depth, group=group, ungrouped_depth=hint)
     elif len(pipe):
         raise RuntimeError("pipelined_features needs an empty pipeline")
     if hasattr(batches, "consumer_lag"):

@@ -108,6 +108,32 @@ def test_depth_loss_vs_reference(dev, B):
     assert rel_l2(pred.grad.cpu().numpy(), g[f"depth_B{B}_grad"]) < 2e-5
 
 
+@pytest.mark.parametrize("B,hw", [(16, (224, 224)), (7, (37, 53)), (20, (40, 56))])
+def test_depth_loss_two_launch_and_four_launch_forms_vs_oracle(dev, B, hw):
+    """DepthLoss (losses.py:97-154) at the timed size (B = 16, 224^2) and a ragged one through the two-launch form (B <= 16: the
+    log-differences of a pixel stay in registers, csrc/loss.hip dlf_*), and B = 20 through the general four-launch form, against the
+    oracle (held to the reference's outputs by tests/golden/losses.npz): loss, gradient, in-place zeroing of targets > max_depth."""
+    from evals.utils.losses import DepthLoss
+    from oracle import losses as ol
+
+    g = torch.Generator().manual_seed(77 + B)
+    pred = torch.rand(B, 1, *hw, generator=g) * 9 + 0.01
+    tgt = torch.rand(B, 1, *hw, generator=g) * 12
+    tgt[torch.rand(B, 1, *hw, generator=g) < 0.15] = 0
+    pr = pred.clone().requires_grad_(True)
+    tr = tgt.clone()
+    ref = ol.depth_loss(pr, tr)
+    ref.backward()
+    p = pred.clone().to(dev).requires_grad_(True)
+    t = tgt.clone().to(dev)
+    loss = DepthLoss()(p, t)
+    loss.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(t.cpu().numpy(), tr.numpy())
+    assert abs(loss.item() - ref.item()) < 2e-6 * abs(ref.item()) + 1e-6
+    assert rel_l2(p.grad.cpu().numpy(), pr.grad.numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("ua", [0, 1])
 def test_angular_loss_vs_reference(dev, ua):
     from evals.utils.losses import angular_loss
