@@ -433,6 +433,17 @@ typedef struct {
 } mvp_upsample_cl_args;
 int mvp_upsample_nearest_cl(const mvp_upsample_cl_args*, void* stream);
 
+/* Backward of "nearest x f upsample, then 3x3 / pad 1 convolution" folded onto the COARSE grid (the DPT probe's out_conv,
+ * probes.py:384-398: F.interpolate(scale_factor=4) then Conv2d(3x3)): box sums of the fine-grid output gradient g [B, H*f, W*f, C]
+ * per coarse pixel and tap, G[(b,i,j), ky*3+kx, c] = sum of g[p, c] over fine pixels p with p + (ky-1, kx-1) in block (i, j), written
+ * as a bf16 pair [B*H*W, 9*C] (out_lo may be null).  Then dW = Gᵀ·x (mvp_gemm_tn_conv, 1x1) and dx = G·Wᵀ (mvp_gemm_bias_act_res)
+ * over the coarse pixels replace the autograd backward of that Conv2d + interpolate pair.  f in {2, 4}; C % 4 == 0. */
+typedef struct {
+  const float* g; mvp_bf16* out_hi; mvp_bf16* out_lo;
+  int B, H, W, C, f; /* H, W = COARSE dims */
+} mvp_upconv_boxsum_args;
+int mvp_upconv3_grad_boxsum(const mvp_upconv_boxsum_args*, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Convolution weight gradient (TN GEMM over pixels, split-K):
  *   dW[n, c, ky, kx] (+)= sum_m G[m, n] * X[pix(m, ky, kx), c]

@@ -83,6 +83,69 @@ __global__ __launch_bounds__(256) void upsample_nearest_cl_bwd(const mvp_upsampl
   }
 }
 
+// ----------------------------------------------------------------------------- backward of "nearest x f, then 3x3 conv" at the COARSE grid
+// y = conv3x3(up_f(x), W) (pad 1): the upsampled input is constant over f x f blocks, so both gradients fold onto the coarse grid.
+// With g = dL/dy on the fine grid and, per coarse pixel (i, j) and tap (ky, kx), the box sum
+//     G[(i,j), tap, co] = sum of g[p, co] over the fine pixels p with p + (ky-1, kx-1) inside block (i, j)   (an f x f box, shifted),
+// dW[co, ci, tap] = sum_(i,j) G[(i,j), tap, co] * x[(i,j), ci]  and  dx[(i,j), ci] = sum_(tap, co) W[co, ci, tap] * G[(i,j), tap, co]:
+// one TN GEMM and one NT GEMM over B*H*W coarse pixels with K = 9*C instead of two convolutions over f^2 as many fine pixels (16x fewer
+// MFMA flops at f = 4: the DPT probe's out_conv, probes.py:384-398).  This kernel makes G (bf16 pair, column tap*C + c): one thread
+// = one coarse pixel x 4 channels, the (f+2)^2 window of g read once per thread (rows left to right, then top to bottom: fixed order).
+template <int F>
+__global__ __launch_bounds__(256) void upconv3_boxsum_kernel(const mvp_upconv_boxsum_args p) {
+  const int C4 = p.C >> 2, Hf = p.H * F, Wf = p.W * F;
+  const int64_t total = (int64_t)p.B * p.H * p.W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int x = (int)(r % p.W); r /= p.W;
+    const int y = (int)(r % p.H);
+    const int64_t b = r / p.H;
+    float4 G[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) G[a][d] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ry = 0; ry < F + 2; ++ry) {
+      const int Y = y * F - 1 + ry;
+      if (Y < 0 || Y >= Hf) continue;
+      float4 v[F + 2];
+#pragma unroll
+      for (int rx = 0; rx < F + 2; ++rx) {
+        const int X = x * F - 1 + rx;
+        v[rx] = (X >= 0 && X < Wf) ? ((const float4*)p.g)[((b * Hf + Y) * Wf + X) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float4 R[3];  // row sums for kx = 0, 1, 2 (dx = -1, 0, +1): window columns [1 - dx, F - dx]
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int rx = 2 - kx; rx < 2 - kx + F; ++rx) { a.x += v[rx].x; a.y += v[rx].y; a.z += v[rx].z; a.w += v[rx].w; }
+        R[kx] = a;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+        if (ry >= 2 - ky && ry < 2 - ky + F) {  // window rows [1 - dy, F - dy]
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) { G[ky][kx].x += R[kx].x; G[ky][kx].y += R[kx].y; G[ky][kx].z += R[kx].z; G[ky][kx].w += R[kx].w; }
+        }
+    }
+    const int64_t row = (b * p.H + y) * p.W + x;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 a = G[ky][kx];
+        uint16_t h[4], l[4];
+        split_bf16(a.x, h[0], l[0]); split_bf16(a.y, h[1], l[1]); split_bf16(a.z, h[2], l[2]); split_bf16(a.w, h[3], l[3]);
+        const int64_t o = (row * 9 + ky * 3 + kx) * C4 + c;
+        ((u32x2_t*)p.out_hi)[o] = u32x2_t{pack2(h[0], h[1]), pack2(h[2], h[3])};
+        if (p.out_lo) ((u32x2_t*)p.out_lo)[o] = u32x2_t{pack2(l[0], l[1]), pack2(l[2], l[3])};
+      }
+  }
+}
+
 // ----------------------------------------------------------------------------- im2col (NCHW fp32 image -> GEMM rows)
 // For convs whose Cin is not a multiple of 32 (the 7x7/2 RGB stem): row m = (b, yo, xo),
 // col k = (ky*kw + kx)*C + c, zero padded up to ldk columns.
@@ -366,6 +429,18 @@ extern "C" int mvp_upsample_nearest_cl(const mvp_upsample_cl_args* a, void* stre
     hipLaunchKernelGGL(upsample_nearest_cl_bwd, dim3(grid_for((int64_t)a->B * a->H * a->W * (a->C >> 2), 8192)), dim3(256), 0, s, *a);
   else
     hipLaunchKernelGGL(upsample_nearest_cl_fwd, dim3(grid_for((int64_t)a->B * a->H * a->W * a->f * a->f * (a->C >> 2), 8192)), dim3(256), 0, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_upconv3_grad_boxsum(const mvp_upconv_boxsum_args* a, void* stream) {
+  if (!a || !a->g || !a->out_hi) return MVP_EINVAL;
+  if (a->B <= 0 || a->H <= 0 || a->W <= 0 || a->C <= 0 || (a->C & 3) || (a->f != 2 && a->f != 4)) return MVP_EINVAL;
+  const int64_t total = (int64_t)a->B * a->H * a->W * (a->C >> 2);
+  if (a->f == 4)
+    hipLaunchKernelGGL(upconv3_boxsum_kernel<4>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(upconv3_boxsum_kernel<2>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

@@ -104,6 +104,14 @@ def upsample_nearest(src: torch.Tensor, B, H, W, C, f, *, want_f32=True, want_pa
     return dst, pair
 
 
+def upconv3_grad_boxsum(g: torch.Tensor, B, H, W, C, f, precision=PREC_BF16X3) -> Pair:
+    """Box sums of the fine-grid gradient ``g`` [B, H*f, W*f, C] of "nearest x f, then 3x3 conv" per COARSE pixel and tap -> bf16 pair
+    [B*H*W, 9*C] (column tap*C + c): the left operand of the coarse-grid weight- and input-gradient GEMMs (csrc/conv.hip)."""
+    out = ops.empty_pair((B * H * W, 9 * C), precision, g.device)
+    lib.call("mvp_upconv3_grad_boxsum", lib.UpconvBoxsumArgs(lib.ptr(g), lib.ptr(out[0]), lib.ptr(out[1]), B, H, W, C, f))
+    return out
+
+
 def mask_split(src: torch.Tensor, mask, M, N, *, ldo=None, write_f32=False, precision=PREC_BF16X3, lds=None, ldm=None):
     """(src * mask) -> bf16 pair [M, ldo] (pad columns zero); optionally written back to src (fp32)."""
     ldo = ldo if ldo is not None else N

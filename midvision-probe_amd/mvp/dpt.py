@@ -158,15 +158,20 @@ class _DPTViT(torch.autograd.Function):
         gh0P = ops.empty_pair((M2, Hd), pr, dev)
         gd = cv.geom(B, H2, W2, LG, 3, 3, 1, 1)
         cv.conv_gemm(gP, gd, cv.pack_weight(w2, 1, pr, pad_cout_to=LG), Hd, relu_mask=ctx.m0, mask_mode=2, out_f32=gh0F, out=gh0P, precision=pr)
-        # ---- out_conv.0 (input = x4 nearest of o0)
-        g2 = cv.geom(B, H2, W2, Hd, 3, 3, 1, 1, up=2)
+        # ---- out_conv.0 (input = x4 nearest of o0): both gradients folded onto the COARSE grid.  The upsampled input is constant over
+        # 4x4 blocks, so with G = the 4x4 box sums of the output gradient per coarse pixel and tap (one pass over gh0, csrc/conv.hip
+        # upconv3_boxsum_kernel), dW = Gᵀ·o0 and d(o0) = G·Wᵀ are GEMMs over the M1 coarse pixels with K = 9·Hd — 16x fewer MFMA
+        # flops than the weight- and input-gradient convolutions over the 16·M1 fine pixels (+ the adjoint of the upsample) they replace.
+        GP = cv.upconv3_grad_boxsum(gh0F, B, H1, W1, Hd, 4, precision=pr)  # [M1, 9*Hd], column tap*Hd + co
+        dw9 = torch.empty(9 * Hd, Hd, 1, 1, dtype=torch.float32, device=dev)
+        cv.conv_dw(GP, 9 * Hd, ctx.o0P, Hd, cv.geom(B, H1, W1, Hd, 1, 1, 1, 0), 9 * Hd, dw9, precision=pr)
         grads[-4] = new_like(w0)
-        cv.conv_dw(gh0P, Hd, ctx.o0P, Hd, g2, Hd, grads[-4], precision=pr)
+        grads[-4].copy_(dw9.view(3, 3, Hd, Hd).permute(2, 3, 0, 1))  # [(ky,kx), co, ci] -> [co, ci, ky, kx]
         grads[-3] = bias_grad(gh0F, Hd)
-        tmp = torch.empty(M2, Hd, dtype=torch.float32, device=dev)
-        cv.conv_gemm(gh0P, g3, cv.pack_weight(w0, 1, pr), Hd, out_f32=tmp, precision=pr)
-        gy, _ = cv.upsample_nearest(tmp, B, H1, W1, Hd, 4, want_pair=False, precision=pr, backward=True)  # [M1, Hd]
-        del tmp, gh0F, gh0P
+        wd = ops.split_bf16(w0.float().permute(1, 2, 3, 0).reshape(Hd, 9 * Hd).contiguous(), pr)  # [ci, (ky, kx, co)]
+        gy = torch.empty(M1, Hd, dtype=torch.float32, device=dev)
+        ops.gemm(GP, wd, M1, Hd, 9 * Hd, out_f32=gy, precision=pr)
+        del GP, gh0F, gh0P
 
         g1 = cv.geom(B, H1, W1, Hd, k, k, 1, k // 2)
 

@@ -149,6 +149,10 @@ class UpsampleClArgs(C.Structure):
                 ("f", _i), ("backward", _i)]
 
 
+class UpconvBoxsumArgs(C.Structure):
+    _fields_ = [("g", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("f", _i)]
+
+
 class DepthMetricsArgs(C.Structure):
     _fields_ = [("pred", _vp), ("gt", _vp), ("out", _vp), ("scale_shift", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
                 ("B", _i), ("HW", _i64), ("scale_invariant", _i)]
@@ -227,6 +231,7 @@ SYMBOLS = {
     "mvp_metrics_breakdown": MetricsBreakdownArgs,
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
+    "mvp_upconv3_grad_boxsum": UpconvBoxsumArgs,
     "mvp_mask_split": MaskSplitArgs,
     "mvp_metrics_workspace_bytes": None,
     "mvp_depth_metrics": DepthMetricsArgs,

@@ -232,3 +232,28 @@ def test_linear_probe_k3_vs_oracle(dev, pt):
     assert rel_l2(y.detach().cpu().numpy(), y_ref.detach().numpy()) < 2e-5
     for n, p in probe.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), sd_r[n].grad.numpy()) < (5e-3 if pt == "bindepth" else 1e-4), n
+
+
+@pytest.mark.parametrize("f,shape", [(4, (2, 5, 7, 128)), (2, (1, 6, 4, 64)), (4, (1, 1, 1, 8))])
+def test_upconv_boxsum_folds_the_backward_of_upsample_then_conv_onto_the_coarse_grid(dev, f, shape):
+    """mvp_upconv3_grad_boxsum: with G = box sums of the fine-grid gradient per coarse pixel and tap, the gradients of
+    y = conv3x3(interpolate(x, scale_factor=f, mode='nearest'), W, padding=1) (probes.py:396-397) are dW = Gᵀ·x and dx = G·Wᵀ over the
+    coarse pixels.  Checked against torch autograd in fp64 on the same graph (image borders included)."""
+    import torch.nn.functional as F
+    from mvp import conv as cv
+
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(3)
+    gy = torch.randn(B, H * f, W * f, C, generator=g)
+    G = cv.upconv3_grad_boxsum(gy.to(dev), B, H, W, C, f, precision=3)
+    Gf = (G[0].float() + G[1].float()).double().cpu().view(B * H * W, 9, C)
+    Cin = 8
+    x = torch.randn(B, Cin, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(C, Cin, 3, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.conv2d(F.interpolate(x, scale_factor=f, mode="nearest"), w, padding=1)
+    y.backward(gy.permute(0, 3, 1, 2).double())
+    xr = x.detach().permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+    dW = torch.einsum("mtc,mi->cit", Gf, xr).reshape(C, Cin, 3, 3)
+    dX = torch.einsum("mtc,cit->mi", Gf, w.detach().reshape(C, Cin, 9)).view(B, H, W, Cin).permute(0, 3, 1, 2)
+    assert float((dW - w.grad).norm() / w.grad.norm()) < 2e-5   # (the pair carries ~16 mantissa bits)
+    assert float((dX - x.grad).norm() / x.grad.norm()) < 2e-5
