@@ -444,6 +444,16 @@ typedef struct {
 } mvp_upconv_boxsum_args;
 int mvp_upconv3_grad_boxsum(const mvp_upconv_boxsum_args*, void* stream);
 
+/* Forward of the same pair from COARSE tap products: t [B*H*W, 9*C] fp32 = x · W_tapᵀ for the 9 taps (ONE GEMM over the coarse pixels,
+ * column tap*C + c); y[p] = act(bias + sum over the taps of t[cell(p + d_tap), tap]) per fine pixel p (taps outside the image = zero
+ * padding), written as the convolution's epilogue would: fp32 and / or bf16 pair [B*H*f*W*f, C], gate mask (post-ReLU value > 0).
+ * act in {MVP_ACT_NONE, MVP_ACT_RELU}; f in {2, 4}; C % 4 == 0. */
+typedef struct {
+  const float* t; const float* bias; float* out_f32; mvp_bf16* out_hi; mvp_bf16* out_lo; uint8_t* out_mask;
+  int B, H, W, C, f, act; /* H, W = COARSE dims */
+} mvp_upconv_gather_args;
+int mvp_upconv3_fwd_gather(const mvp_upconv_gather_args*, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Convolution weight gradient (TN GEMM over pixels, split-K):
  *   dW[n, c, ky, kx] (+)= sum_m G[m, n] * X[pix(m, ky, kx), c]

@@ -29,7 +29,7 @@ extern "C" int mvp_sizeof(const char* name) {
   MVP_SZ(mvp_info_t) MVP_SZ(mvp_split_bf16_args) MVP_SZ(mvp_patch_gather_args) MVP_SZ(mvp_gemm_args) MVP_SZ(mvp_layernorm_args)
   MVP_SZ(mvp_attention_args) MVP_SZ(mvp_cls_rows_args) MVP_SZ(mvp_bn_tokens_args) MVP_SZ(mvp_pack_nchw_args) MVP_SZ(mvp_resize_args)
   MVP_SZ(mvp_depth_predict_args) MVP_SZ(mvp_depth_loss_args) MVP_SZ(mvp_angular_loss_args) MVP_SZ(mvp_colsum_args) MVP_SZ(mvp_adamw_args)
-  MVP_SZ(mvp_corr_argmax_args) MVP_SZ(mvp_conv_weight_pack_args) MVP_SZ(mvp_upsample_cl_args) MVP_SZ(mvp_upconv_boxsum_args) MVP_SZ(mvp_gemm_tn_args)
+  MVP_SZ(mvp_corr_argmax_args) MVP_SZ(mvp_conv_weight_pack_args) MVP_SZ(mvp_upsample_cl_args) MVP_SZ(mvp_upconv_boxsum_args) MVP_SZ(mvp_upconv_gather_args) MVP_SZ(mvp_gemm_tn_args)
   MVP_SZ(mvp_depth_metrics_args) MVP_SZ(mvp_snorm_metrics_args) MVP_SZ(mvp_linear_bins_args) MVP_SZ(mvp_im2col_args)
   MVP_SZ(mvp_maxpool_cl_args) MVP_SZ(mvp_mask_split_args) MVP_SZ(mvp_metrics_breakdown_args) MVP_SZ(mvp_argmax_2d_args) MVP_SZ(mvp_scale_shift_args) MVP_SZ(mvp_stem_args) MVP_SZ(mvp_bn_running_update_args)
 #undef MVP_SZ

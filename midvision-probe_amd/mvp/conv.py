@@ -104,6 +104,20 @@ def upsample_nearest(src: torch.Tensor, B, H, W, C, f, *, want_f32=True, want_pa
     return dst, pair
 
 
+def upconv3_forward(x: Pair, w: torch.Tensor, bias, B, H, W, f, *, act=lib.ACT_NONE, out: Optional[Pair] = None, out_mask=None, out_f32=None,
+                    precision=PREC_BF16X3) -> None:
+    """y = act(conv3x3(nearest_upsample(x, f), w, padding=1) + bias) WITHOUT the convolution over the fine grid: the 9 per-tap products
+    of every COARSE pixel in one GEMM (x [B*H*W, C] pair · [9*Cout, C]ᵀ), then a gather-sum per fine pixel (csrc/conv.hip
+    upconv3_gather_kernel) that writes the pair / mask / fp32 outputs [B*H*f*W*f, Cout]."""
+    Cout, C = w.shape[0], w.shape[1]
+    wt = ops.split_bf16(w.detach().float().permute(2, 3, 0, 1).reshape(9 * Cout, C).contiguous(), precision)  # [(ky, kx, co), ci]
+    t = torch.empty(B * H * W, 9 * Cout, dtype=torch.float32, device=w.device)
+    ops.gemm(x, wt, B * H * W, 9 * Cout, C, out_f32=t, precision=precision)
+    o_hi, o_lo = out if out is not None else (None, None)
+    lib.call("mvp_upconv3_fwd_gather", lib.UpconvGatherArgs(lib.ptr(t), lib.ptr(bias), lib.ptr(out_f32), lib.ptr(o_hi), lib.ptr(o_lo), lib.ptr(out_mask),
+                                                            B, H, W, Cout, f, act))
+
+
 def upconv3_grad_boxsum(g: torch.Tensor, B, H, W, C, f, precision=PREC_BF16X3) -> Pair:
     """Box sums of the fine-grid gradient ``g`` [B, H*f, W*f, C] of "nearest x f, then 3x3 conv" per COARSE pixel and tap -> bf16 pair
     [B*H*W, 9*C] (column tap*C + c): the left operand of the coarse-grid weight- and input-gradient GEMMs (csrc/conv.hip)."""

@@ -98,12 +98,12 @@ class _DPTViT(torch.autograd.Function):
                 out = rcu(out[0], out[1], wa, ba, wb, bb)
         o0P = out[1]
 
-        # ---- out_conv: x4 nearest folded into the addressing of the first 3x3
+        # ---- out_conv: the x4 nearest upsample + first 3x3 evaluated from the coarse grid's per-tap products (cv.upconv3_forward: one
+        # GEMM over M1 coarse pixels with N = 9*Hd, then a gather-sum per fine pixel) instead of a convolution over 16x as many pixels
         w0, b0, w2, b2 = det[-4:]
-        g2 = cv.geom(B, H2, W2, Hd, 3, 3, 1, 1, up=2)
         h0P = ops.empty_pair((M2, Hd), pr, dev)
         m0 = torch.empty(M2, Hd, dtype=torch.uint8, device=dev)
-        cv.conv_gemm(o0P, g2, cv.pack_weight(w0, 0, pr), Hd, bias=b0.float().contiguous(), act=ACT_RELU, out=h0P, out_mask=m0, precision=pr)
+        cv.upconv3_forward(o0P, w0, b0.float().contiguous(), B, H1, W1, 4, act=ACT_RELU, out=h0P, out_mask=m0, precision=pr)
         g3 = cv.geom(B, H2, W2, Hd, 3, 3, 1, 1)
         b2p = torch.cat([b2.float(), b2.new_zeros(K4 - Cout).float()]) if K4 != Cout else b2.float().contiguous()
         logits = torch.empty(B, H2, W2, K4, dtype=torch.float32, device=dev)

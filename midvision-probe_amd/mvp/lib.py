@@ -153,6 +153,11 @@ class UpconvBoxsumArgs(C.Structure):
     _fields_ = [("g", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("f", _i)]
 
 
+class UpconvGatherArgs(C.Structure):
+    _fields_ = [("t", _vp), ("bias", _vp), ("out_f32", _vp), ("out_hi", _vp), ("out_lo", _vp), ("out_mask", _vp),
+                ("B", _i), ("H", _i), ("W", _i), ("C", _i), ("f", _i), ("act", _i)]
+
+
 class DepthMetricsArgs(C.Structure):
     _fields_ = [("pred", _vp), ("gt", _vp), ("out", _vp), ("scale_shift", _vp), ("workspace", _vp), ("workspace_bytes", _i64),
                 ("B", _i), ("HW", _i64), ("scale_invariant", _i)]
@@ -232,6 +237,7 @@ SYMBOLS = {
     "mvp_conv_weight_pack": ConvWeightPackArgs,
     "mvp_upsample_nearest_cl": UpsampleClArgs,
     "mvp_upconv3_grad_boxsum": UpconvBoxsumArgs,
+    "mvp_upconv3_fwd_gather": UpconvGatherArgs,
     "mvp_mask_split": MaskSplitArgs,
     "mvp_metrics_workspace_bytes": None,
     "mvp_depth_metrics": DepthMetricsArgs,

@@ -76,7 +76,7 @@ def test_ctypes_structs_match_the_compiled_header():
         "mvp_snorm_metrics_args": lib.SnormMetricsArgs, "mvp_linear_bins_args": lib.LinearBinsArgs, "mvp_im2col_args": lib.Im2colArgs,
         "mvp_maxpool_cl_args": lib.MaxpoolClArgs, "mvp_mask_split_args": lib.MaskSplitArgs,
         "mvp_metrics_breakdown_args": lib.MetricsBreakdownArgs, "mvp_argmax_2d_args": lib.Argmax2dArgs, "mvp_scale_shift_args": lib.ScaleShiftArgs, "mvp_stem_args": lib.StemArgs,
-        "mvp_bn_running_update_args": lib.BnRunningUpdateArgs, "mvp_upconv_boxsum_args": lib.UpconvBoxsumArgs,
+        "mvp_bn_running_update_args": lib.BnRunningUpdateArgs, "mvp_upconv_boxsum_args": lib.UpconvBoxsumArgs, "mvp_upconv_gather_args": lib.UpconvGatherArgs,
     }
     import re
     header = open(os.path.join(os.path.dirname(__file__), "..", "include", "mvp_hip.h")).read()

@@ -257,3 +257,31 @@ def test_upconv_boxsum_folds_the_backward_of_upsample_then_conv_onto_the_coarse_
     dX = torch.einsum("mtc,cit->mi", Gf, w.detach().reshape(C, Cin, 9)).view(B, H, W, Cin).permute(0, 3, 1, 2)
     assert float((dW - w.grad).norm() / w.grad.norm()) < 2e-5   # (the pair carries ~16 mantissa bits)
     assert float((dX - x.grad).norm() / x.grad.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("f,shape,cout", [(4, (2, 5, 7, 128), 128), (2, (1, 6, 4, 128), 256)])
+def test_upconv_forward_from_coarse_tap_products(dev, f, shape, cout):
+    """cv.upconv3_forward = relu(conv3x3(interpolate(x, scale_factor=f, mode='nearest'), W, padding=1) + b) (probes.py:396-397) computed as
+    per-tap products on the coarse grid + a gather-sum per fine pixel: against torch in fp64 (borders included), pair / fp32 / gate
+    mask outputs consistent with each other."""
+    import torch.nn.functional as F
+    from mvp import conv as cv, lib, ops
+
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(cout, C, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    xP = ops.split_bf16(x.reshape(-1, C).to(dev), 3)
+    M = B * H * f * W * f
+    oP = ops.empty_pair((M, cout), 3, dev)
+    o32 = torch.empty(M, cout, dtype=torch.float32, device=dev)
+    om = torch.empty(M, cout, dtype=torch.uint8, device=dev)
+    cv.upconv3_forward(xP, w.to(dev), b.to(dev), B, H, W, f, act=lib.ACT_RELU, out=oP, out_mask=om, out_f32=o32, precision=3)
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2).double(), scale_factor=f, mode="nearest"), w.double(), b.double(), padding=1).relu()
+    ref = ref.permute(0, 2, 3, 1).reshape(M, cout)
+    got = o32.double().cpu()
+    assert float((got - ref).norm() / ref.norm()) < 2e-5
+    assert torch.equal(om.cpu().bool(), got > 0)
+    pair = (oP[0].float() + oP[1].float()).double().cpu()
+    assert float((pair - got).abs().max()) < 2e-4 * float(got.abs().max())

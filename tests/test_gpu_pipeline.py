@@ -439,6 +439,32 @@ def test_span_forwards_are_bit_identical_to_serial(span, graphs, n):
     assert [int(b.num_batches_tracked) for b in model.batchnorms] == [n] * 4
 
 
+@pytest.mark.parametrize("output", ["dense", "dense-cls"])
+def test_span_forwards_in_eval_mode_return_each_batchs_own_features(output):
+    """validate()'s shape: the backbone in eval mode (tap BN from running statistics, no deferred updates), spans of 7 images over
+    batches of 4: every batch's features equal ``model(images)`` of that batch alone, bit for bit, 'dense-cls' (the tap kernel's CLS
+    output next to the map) included."""
+    from evals.models.dino import DINO
+    from mvp import backbone as bb
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+
+    dev = torch.device("cuda:0")
+    model = DINO(return_multilayer=True, add_norm=True, output=output, weights=bb.random_vit_state_dict(seed=3)).to(dev)
+    for i, bnm in enumerate(model.batchnorms):  # non-trivial running statistics
+        g = torch.Generator().manual_seed(40 + i)
+        bnm.running_mean.copy_(torch.randn(bnm.running_mean.shape, generator=g).to(dev) * 0.1)
+        bnm.running_var.copy_((torch.rand(bnm.running_var.shape, generator=g) + 0.5).to(dev))
+    model.eval()
+    bs = _batches(dev, 6)
+    ref = [[t.clone() for t in model(b["image"])] for b in bs]
+    pipe = FeaturePipeline(model, 2, graphs=True, group=2, span=7)
+    got = [[t.clone() for t in f] for _, f in pipelined_features(model, bs, pipe=pipe)]
+    assert pipe.span == 7 and len(got) == 6
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def test_default_span_of_the_timed_configuration():
     """B = 16 at 224^2 on ViT-B/16: 110 images per forward (21670 rows = 85 x 3 tiles of 256^2: one round of 256 CUs for the
     N = 768 GEMMs); 480x640 (1201 rows per image): single batches on three streams, as before (measured faster than 18-image spans)."""
