@@ -69,21 +69,27 @@ class _DPTViT(torch.autograd.Function):
             f = torch.empty(M0, Hd, dtype=torch.float32, device=dev)
             a = (pack.tok[0][:, i * C:], pack.tok[1][:, i * C:] if pack.tok[1] is not None else None)
             ops.gemm(a, wi, M0, Hd, C, bias=det[2 * i + 1].float().contiguous(), out_f32=f, precision=pr, lda=pack.Cpad)
-            u.append(cv.upsample_nearest(f, B, h, w, Hd, 2, precision=pr))  # (fp32, pair) at H1 x W1
+            # (fp32, pair) at H1 x W1, and the COARSE pair: a 3x3 unit's first conv reads the x2 map through its coarse tap products
+            u.append(cv.upsample_nearest(f, B, h, w, Hd, 2, precision=pr, want_pair=(k != 3)) + (ops.split_bf16(f, pr) if k == 3 else None,))
 
         g1 = cv.geom(B, H1, W1, Hd, k, k, 1, k // 2)
         saved_rcu = []
 
-        def rcu(xF, xP, wa, ba, wb, bb, extra=None):
+        def rcu(xF, xP, wa, ba, wb, bb, extra=None, coarse=None):
+            """``coarse``: the unit's input is the nearest x2 of this [M0, Hd] pair (u_blk): its first 3x3 conv then runs from the coarse
+            grid's tap products (cv.upconv3_forward) and its backward folds onto the coarse grid (rcu_bwd)."""
             aP = ops.empty_pair((M1, Hd), pr, dev)
             ma = torch.empty(M1, Hd, dtype=torch.uint8, device=dev)
-            cv.conv_gemm(xP, g1, cv.pack_weight(wa, 0, pr), Hd, bias=ba.float().contiguous(), act=ACT_RELU, out=aP, out_mask=ma, precision=pr)
+            if coarse is not None:
+                cv.upconv3_forward(coarse, wa, ba.float().contiguous(), B, h, w, 2, act=ACT_RELU, out=aP, out_mask=ma, precision=pr)
+            else:
+                cv.conv_gemm(xP, g1, cv.pack_weight(wa, 0, pr), Hd, bias=ba.float().contiguous(), act=ACT_RELU, out=aP, out_mask=ma, precision=pr)
             yF = torch.empty(M1, Hd, dtype=torch.float32, device=dev)
             yP = ops.empty_pair((M1, Hd), pr, dev)
             mb = torch.empty(M1, Hd, dtype=torch.uint8, device=dev)
             cv.conv_gemm(aP, g1, cv.pack_weight(wb, 0, pr), Hd, bias=bb.float().contiguous(), act=ACT_RELU, residual=xF, residual2=extra,
                          out_f32=yF, out=yP, out_mask=mb, precision=pr)
-            saved_rcu.append((xP, aP, ma, mb))
+            saved_rcu.append((xP, aP, ma, mb, coarse))
             return yF, yP
 
         base = 8
@@ -91,9 +97,9 @@ class _DPTViT(torch.autograd.Function):
         for n, (blk, unit) in enumerate(RCU_ORDER):
             wa, ba, wb, bb = det[base + 4 * n: base + 4 * n + 4]
             if unit == 1:      # x = RCU1(f_blk) + out
-                out = rcu(u[blk][0], u[blk][1], wa, ba, wb, bb, extra=out[0])
+                out = rcu(u[blk][0], u[blk][1], wa, ba, wb, bb, extra=out[0], coarse=u[blk][2])
             elif blk == 3:     # ref_3 has no skip unit: RCU2 acts on f_3
-                out = rcu(u[3][0], u[3][1], wa, ba, wb, bb)
+                out = rcu(u[3][0], u[3][1], wa, ba, wb, bb, coarse=u[3][2])
             else:
                 out = rcu(out[0], out[1], wa, ba, wb, bb)
         o0P = out[1]
@@ -176,7 +182,7 @@ class _DPTViT(torch.autograd.Function):
         g1 = cv.geom(B, H1, W1, Hd, k, k, 1, k // 2)
 
         def rcu_bwd(gy, saved, idx):
-            xP, aP, ma, mb = saved
+            xP, aP, ma, mb, coarse = saved
             wa, ba, wb, bb = det[idx: idx + 4]
             grF = torch.empty(M1, Hd, dtype=torch.float32, device=dev)
             grP = ops.empty_pair((M1, Hd), pr, dev)
@@ -189,21 +195,33 @@ class _DPTViT(torch.autograd.Function):
             gaP = ops.empty_pair((M1, Hd), pr, dev)
             cv.conv_gemm(grP, g1, cv.pack_weight(wb, 1, pr), Hd, relu_mask=ma, mask_mode=2, out_f32=gaF, out=gaP, precision=pr)
             grads[idx] = new_like(wa)
-            cv.conv_dw(gaP, Hd, xP, Hd, g1, Hd, grads[idx], precision=pr)
             grads[idx + 1] = bias_grad(gaF, Hd)
+            if coarse is not None:
+                # input = nearest x2 of a coarse map: both gradients on the coarse grid (box sums of ga per coarse pixel and tap), and the
+                # unit's input gradient is only ever needed summed over the 2x2 blocks (adjoint of the upsample): gf = G·Wᵀ + blocksum(gy)
+                GP = cv.upconv3_grad_boxsum(gaF, B, h, w, Hd, 2, precision=pr)
+                dw9 = torch.empty(9 * Hd, Hd, 1, 1, dtype=torch.float32, device=dev)
+                cv.conv_dw(GP, 9 * Hd, coarse, Hd, cv.geom(B, h, w, Hd, 1, 1, 1, 0), 9 * Hd, dw9, precision=pr)
+                grads[idx].copy_(dw9.view(3, 3, Hd, Hd).permute(2, 3, 0, 1))
+                gyc, _ = cv.upsample_nearest(gy, B, h, w, Hd, 2, want_pair=False, precision=pr, backward=True)
+                wd = ops.split_bf16(wa.float().permute(1, 2, 3, 0).reshape(Hd, 9 * Hd).contiguous(), pr)
+                gf = torch.empty(M0, Hd, dtype=torch.float32, device=dev)
+                ops.gemm(GP, wd, M0, Hd, 9 * Hd, residual=gyc, out_f32=gf, precision=pr)
+                return gf, True
+            cv.conv_dw(gaP, Hd, xP, Hd, g1, Hd, grads[idx], precision=pr)
             gx = torch.empty(M1, Hd, dtype=torch.float32, device=dev)
             cv.conv_gemm(gaP, g1, cv.pack_weight(wa, 1, pr), Hd, residual=gy, out_f32=gx, precision=pr)
-            return gx
+            return gx, False
 
         g_u: List[Optional[torch.Tensor]] = [None] * 4
         base = 8
         for n in reversed(range(len(RCU_ORDER))):
             blk, unit = RCU_ORDER[n]
-            gx = rcu_bwd(gy, ctx.saved_rcu[n], base + 4 * n)
+            gx, on_coarse = rcu_bwd(gy, ctx.saved_rcu[n], base + 4 * n)
             if unit == 1:
-                g_u[blk] = gx      # gradient of the upsampled f_blk; the "+ out" branch receives gy unchanged
+                g_u[blk] = (gx, on_coarse)  # gradient of the upsampled f_blk (or already of f_blk); the "+ out" branch receives gy unchanged
             elif blk == 3:
-                g_u[3] = gx
+                g_u[3] = (gx, on_coarse)
             else:
                 gy = gx            # RCU2's input is the fusion sum x = RCU1(f) + out: both addends get gx
                 continue
@@ -213,7 +231,10 @@ class _DPTViT(torch.autograd.Function):
         # ---- conv_i (1x1): adjoint of nearest x2, then dW over the packed feature tokens
         g0 = cv.geom(B, h, w, C, 1, 1, 1, 0)
         for i in range(4):
-            gfF, gfP = cv.upsample_nearest(g_u[i], B, h, w, Hd, 2, precision=pr, backward=True)
+            if g_u[i][1]:
+                gfF, gfP = g_u[i][0], ops.split_bf16(g_u[i][0], pr)
+            else:
+                gfF, gfP = cv.upsample_nearest(g_u[i][0], B, h, w, Hd, 2, precision=pr, backward=True)
             grads[2 * i] = new_like(det[2 * i])
             x = (pack.tok[0][:, i * C:], pack.tok[1][:, i * C:] if pack.tok[1] is not None else None)
             cv.conv_dw(gfP, Hd, x, pack.Cpad, g0, Hd, grads[2 * i], precision=pr)

@@ -123,7 +123,7 @@ def _dpt_fp64_with_masks(sd, feats, ctx, B, h, w):
     f = [F.interpolate(F.conv2d(feats[i].double(), P[f"head.conv_{i}.weight"], P[f"head.conv_{i}.bias"]), scale_factor=2) for i in range(4)]
 
     def rcu(x, pre, n):
-        _, _, ma, mb = ctx.saved_rcu[n]
+        _, _, ma, mb = ctx.saved_rcu[n][:4]
         a = _MaskedRelu.apply(F.conv2d(x, P[pre + "conv.0.weight"], P[pre + "conv.0.bias"], padding=1), cl(ma, H1, W1))
         return _MaskedRelu.apply(F.conv2d(a, P[pre + "conv.2.weight"], P[pre + "conv.2.bias"], padding=1), cl(mb, H1, W1)) + x
 
