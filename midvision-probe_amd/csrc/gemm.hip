@@ -545,6 +545,9 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
       if (t128 <= 512 || t128 >= 1536) return launch_gemm<128, 128, 64, 3, 1, false, 8>(a, s);
       return launch_gemm<64, 128, 64, 3, 1>(a, s);
     }
+    // long-K, mid-N GEMMs with many tiles (the DPT probe's coarse-grid input gradients: M = 12544, N = 512, K = 4608): the tile the
+    // convolutions of the same shape use (165 us against 244 on 128x64)
+    if (a->K >= 4096 && t128 >= 300) return launch_gemm<128, 128, 64, 3, 1, false, 8>(a, s);
     const long t64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64);
     if (t64 <= 1280) return launch_gemm<64, 64, 64, 3, 1>(a, s);  // 5 resident per CU
     return launch_gemm<128, 64, 64, 3, 1>(a, s);

@@ -74,6 +74,8 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
             return "128, 128, 64, 3, 1"
         if N >= 1024:
             return "128, 128, 64, 3, 1" if (t128 <= 512 or t128 >= 1536) else "64, 128, 64, 3, 1"
+        if K >= 4096 and t128 >= 300:
+            return "128, 128, 64, 3, 1"
         t64 = ((M + 63) // 64) * ((N + 63) // 64)
         return "64, 64, 64, 3, 1" if t64 <= 1280 else "128, 64, 64, 3, 1"
     return "128, 128, 64, 1, 2" if t128 >= 400 else "64, 64, 64, 1, 2"

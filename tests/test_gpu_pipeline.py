@@ -439,6 +439,34 @@ def test_span_forwards_are_bit_identical_to_serial(span, graphs, n):
     assert [int(b.num_batches_tracked) for b in model.batchnorms] == [n] * 4
 
 
+def test_span_forwards_with_a_ragged_last_batch():
+    """An epoch whose last batch is smaller (drop_last=False): the span that would run into it ends on the batch boundary instead, and
+    the ragged batch runs as a forward of its own — five batches of 4 and one of 3, spans of 6 images: forwards of 6, 6, 6, 2 and 3
+    images.  Trajectory = the one-batch-at-a-time loop's, bit for bit."""
+    from evals.utils.losses import DepthLoss
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+    from mvp.train import train_depth_step
+
+    dev = torch.device("cuda:0")
+
+    def run(span):
+        model, probe, opt, sched = _build(dev)
+        bs = _batches(dev, 6)
+        bs[-1] = {k: v[:3].contiguous() for k, v in bs[-1].items()}
+        pipe = FeaturePipeline(model, 2 if span else 1, graphs=bool(span), group=2 if span else 1, span=span or None)
+        losses = [train_depth_step(model, probe, opt, sched, DepthLoss(), None, b["depth"].clone(), feats=f)
+                  for b, f in pipelined_features(model, bs, pipe=pipe)]
+        torch.cuda.synchronize()
+        return (torch.stack(losses).cpu().numpy(), opt.flat_param.cpu().numpy().copy(),
+                [torch.cat([m.running_mean, m.running_var]).cpu().numpy() for m in model.batchnorms])
+
+    ref, got = run(0), run(6)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("output", ["dense", "dense-cls"])
 def test_span_forwards_in_eval_mode_return_each_batchs_own_features(output):
     """validate()'s shape: the backbone in eval mode (tap BN from running statistics, no deferred updates), spans of 7 images over
