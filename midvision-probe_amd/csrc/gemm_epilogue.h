@@ -225,7 +225,9 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
 //     order, so a residual load issued behind a store waits for that store's whole round trip (the generic loop did that once per
 //     row group: a dependent load -> store -> load chain).
 // N % 8 == 0 and 16-byte-aligned rows are required (the caller checks and falls back to gemm_epilogue()).
-template <int NT, int MT, int WN, int ACT, bool RES, bool F32OUT, bool PAIR>
+// GATE: the backward of a ReLU fused into an input-gradient GEMM (mask_mode 2: v *= the stored byte gate; the DPT probe's
+// out_conv[2] input gradient, 200 704 x 512 outputs) — the 8 gate bytes of a lane are one 8-byte load, prefetched like the residual.
+template <int NT, int MT, int WN, int ACT, bool RES, bool F32OUT, bool PAIR, bool GATE = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
                                                    const int m0, const int n0, const int wm0, const int wn0) {
   static_assert(WN == 64 && NT == 4 && (MT % 2) == 0, "wave tile 32k x 64");
@@ -252,10 +254,13 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
   // the probe step's small kernels run beside the frozen forward and need that room).
   constexpr int HIT = 2;
   float4 rpre[HIT][2];
-  auto load_res = [&](int u) {  // residual rows of 16-row unit u (u = 0 .. MT - 1)
+  uint64_t gpre[HIT];
+  auto load_res = [&](int u) {  // residual rows (and gate bytes) of 16-row unit u (u = 0 .. MT - 1)
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       const int m = m0 + wm0 + u * 16 + it * 8 + er;
+      if (GATE) gpre[it] = (m < p.M && col_ok) ? *(const uint64_t*)(p.relu_mask + (size_t)out_row(m) * p.ldm + ncol) : 0ull;
+      if (!RES) continue;
       rpre[it][0] = rpre[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < p.M && col_ok) {
         const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : out_row(m);
@@ -265,7 +270,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
       }
     }
   };
-  if (RES) load_res(0);
+  if (RES || GATE) load_res(0);
 #pragma unroll
   for (int h = 0; h < MT / 2; ++h) {
     // accumulators -> LDS (lane: row frow of the m-fragment, columns i*16 + 4*fq ..)
@@ -287,12 +292,16 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
         }
+        if (GATE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[it][e] *= ((gpre[it] >> (8 * e)) & 0xffull) ? 1.f : 0.f;
+        }
         if (RES) {
           v[it][0] += rpre[it][0].x; v[it][1] += rpre[it][0].y; v[it][2] += rpre[it][0].z; v[it][3] += rpre[it][0].w;
           v[it][4] += rpre[it][1].x; v[it][5] += rpre[it][1].y; v[it][6] += rpre[it][1].z; v[it][7] += rpre[it][1].w;
         }
       }
-      if (RES && u + 1 < MT) load_res(u + 1);  // issued BEFORE this unit's stores: its data never waits behind them
+      if ((RES || GATE) && u + 1 < MT) load_res(u + 1);  // issued BEFORE this unit's stores: its data never waits behind them
 #pragma unroll
       for (int it = 0; it < HIT; ++it) {
         const int m = m0 + wm0 + u * 16 + it * 8 + er;
@@ -323,7 +332,11 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
 }
 
 // Which wide-epilogue instantiation serves these arguments (0 = none: the generic epilogue).
-__device__ __forceinline__ int gemm_epilogue_wide_variant(const mvp_gemm_args& p) {
+__host__ __device__ __forceinline__ int gemm_epilogue_wide_variant(const mvp_gemm_args& p) {
+  if (p.relu_mask && p.mask_mode == 2 && !p.out_mask && !p.residual2 && !p.act_after_res && !p.residual_hi && !p.residual && p.act == MVP_ACT_NONE &&
+      p.out_f32 && !p.out_hi && !(p.N & 7) && !(p.ldm & 7) && !((size_t)p.relu_mask & 7) && !(p.ldo & 3) && !((size_t)p.out_f32 & 15) &&
+      !(p.bias && ((size_t)p.bias & 15)))
+    return 6;  // gated input gradient, fp32 out
   if (p.relu_mask || p.out_mask || p.residual2 || p.act_after_res || p.residual_hi) return 0;
   if ((p.N & 7) || (p.act != MVP_ACT_NONE && p.act != MVP_ACT_GELU)) return 0;
   if (p.residual && ((p.ldr & 3) || ((size_t)p.residual & 15))) return 0;

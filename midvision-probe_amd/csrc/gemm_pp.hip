@@ -337,6 +337,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
     case 3: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, true, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
     case 4: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
     case 5: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
+    case 6: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false, true>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
     default: gemm_epilogue<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0);
   }
 #if MVP_PP_STAMP
@@ -360,7 +361,8 @@ int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-  const bool ext = a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi;
+  // (the gated-input-gradient combination has a wide epilogue of its own in the plain instantiation)
+  const bool ext = (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) && gemm_epilogue_wide_variant(*a) != 6;
   if (ext)
     hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true, CONV>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
   else

@@ -160,10 +160,9 @@ class _DPTViT(torch.autograd.Function):
         grads[-2] = new_like(w2)
         cv.conv_dw(gP, LG, ctx.h0P, Hd, g3, Cout, grads[-2], precision=pr)
         grads[-1] = bias_grad(g_logits, K4, Cout)
-        gh0F = torch.empty(M2, Hd, dtype=torch.float32, device=dev)
-        gh0P = ops.empty_pair((M2, Hd), pr, dev)
+        gh0F = torch.empty(M2, Hd, dtype=torch.float32, device=dev)  # (fp32 only: its consumers are the box sums and the bias gradient)
         gd = cv.geom(B, H2, W2, LG, 3, 3, 1, 1)
-        cv.conv_gemm(gP, gd, cv.pack_weight(w2, 1, pr, pad_cout_to=LG), Hd, relu_mask=ctx.m0, mask_mode=2, out_f32=gh0F, out=gh0P, precision=pr)
+        cv.conv_gemm(gP, gd, cv.pack_weight(w2, 1, pr, pad_cout_to=LG), Hd, relu_mask=ctx.m0, mask_mode=2, out_f32=gh0F, precision=pr)
         # ---- out_conv.0 (input = x4 nearest of o0): both gradients folded onto the COARSE grid.  The upsampled input is constant over
         # 4x4 blocks, so with G = the 4x4 box sums of the output gradient per coarse pixel and tap (one pass over gh0, csrc/conv.hip
         # upconv3_boxsum_kernel), dW = Gᵀ·o0 and d(o0) = G·Wᵀ are GEMMs over the M1 coarse pixels with K = 9·Hd — 16x fewer MFMA
@@ -177,7 +176,7 @@ class _DPTViT(torch.autograd.Function):
         wd = ops.split_bf16(w0.float().permute(1, 2, 3, 0).reshape(Hd, 9 * Hd).contiguous(), pr)  # [ci, (ky, kx, co)]
         gy = torch.empty(M1, Hd, dtype=torch.float32, device=dev)
         ops.gemm(GP, wd, M1, Hd, 9 * Hd, out_f32=gy, precision=pr)
-        del GP, gh0F, gh0P
+        del GP, gh0F
 
         g1 = cv.geom(B, H1, W1, Hd, k, k, 1, k // 2)
 
@@ -192,7 +191,7 @@ class _DPTViT(torch.autograd.Function):
             cv.conv_dw(grP, Hd, aP, Hd, g1, Hd, grads[idx + 2], precision=pr)
             grads[idx + 3] = bias_grad(grF, Hd)
             gaF = torch.empty(M1, Hd, dtype=torch.float32, device=dev)
-            gaP = ops.empty_pair((M1, Hd), pr, dev)
+            gaP = ops.empty_pair((M1, Hd), pr, dev) if coarse is None else None  # (the coarse path reads the fp32 gradient only)
             cv.conv_gemm(grP, g1, cv.pack_weight(wb, 1, pr), Hd, relu_mask=ma, mask_mode=2, out_f32=gaF, out=gaP, precision=pr)
             grads[idx] = new_like(wa)
             grads[idx + 1] = bias_grad(gaF, Hd)
