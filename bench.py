@@ -186,7 +186,10 @@ def flops_per_image(N: int, D: int = 768, depth: int = 12, head_out: int = 256, 
     (token resolution, conv1x1 and bilinear commute) fwd + dW = 2 * 2*(N-1)*taps*D*head_out.
     DPT probe (probes.py:215-399): 4 conv1x1 D->hidden at the token grid, 14 conv3x3 hidden->hidden at twice the grid,
     out_conv 3x3 hidden->hidden and 3x3 hidden->head_out at 8x the grid; backward = bwd-data + bwd-weight of each (no bwd-data
-    into the detached features): ~142 GF forward, ~424 GF per image and step at 224^2."""
+    into the detached features): ~142 GF forward, ~424 GF per image and step at 224^2.  These are the REFERENCE algorithm's flops (what
+    `chip_level` divides by the step time: throughput in the reference's own arithmetic); since round 3 the library executes fewer — the
+    3x3 convs that read a nearest-upsampled map run on the coarse grid (DESIGN §4 "Convolutions": out_conv[0] 947 -> 237 GF forward,
+    2 x 947 -> 2 x 59 GF backward per 16 images) — so `chip_level` of a `--probe dpt` line is not an MFMA utilisation."""
     vit = depth * (N * (2 * (3 * D * D + D * D + 8 * D * D)) + 4 * N * N * D) + (N - 1) * 2 * D * D
     if probe == "dpt":
         hw = N - 1
