@@ -39,12 +39,16 @@ from __future__ import annotations
 
 import collections
 import contextlib
+import itertools
 import os
 from typing import Iterable, Iterator, Tuple
 
 import torch
 
-Span = collections.namedtuple("Span", "batch carry")  # a forward over a span of the image stream: images per batch, images of the cut batch carried in
+# a forward over a span of the image stream: images per batch, images of the cut batch carried in, id of the stream (= the pipeline's
+# namespace: the engine keeps one carry store per stream, so two pipelines over one backbone — a training loop suspended at a cut batch
+# and a validation pass — never see each other's rows)
+Span = collections.namedtuple("Span", "batch carry stream", defaults=(0,))
 
 _SLOT = 0  # slot of the forward being enqueued (host state; kernels are enqueued by one host thread)
 _GROUPS = 1  # batches stacked into the forward being enqueued
@@ -54,7 +58,11 @@ SHARED_TILES_FROM = 3
 MAX_STREAMS = 3  # side streams = kernel chains running side by side; more than 3 measured slower (4: -14 %)
 
 
-def current_slot() -> int:
+_NAMESPACES = itertools.count(1)  # one per FeaturePipeline: its slots' buffers are its own (two pipelines over one backbone do not collide)
+
+
+def current_slot():
+    """Key of the buffer set the forward being enqueued owns: 0 outside a pipeline, (pipeline namespace, slot index) inside."""
     return _SLOT
 
 
@@ -268,6 +276,7 @@ class FeaturePipeline:
         if self.depth == 1:
             self.group = 1
         # images per span forward (module docstring, "Spans"): None = default_span when ``group`` is chosen automatically, else off
+        self._ns = next(_NAMESPACES)
         self._span_arg = span
         # depth to fall to when ``depth`` is None and the forwards turn out to be single batches (``default_depth(probe)``: a DPT probe
         # step gains from grouped forwards beside it, 762 -> 802 img/s, but loses to single-batch ones, 739-748 -> 699-723)
@@ -343,7 +352,7 @@ class FeaturePipeline:
 
     # ------------------------------------------------------------------ one forward on a slot's stream
     def _eager(self, slot: int, images: torch.Tensor, groups: int = 1):
-        with _slot(slot, self.chains, groups):
+        with _slot((self._ns, slot), self.chains, groups):
             _take_deferred()
             feats = _extract(self.model, images)
             return feats, _take_deferred()
@@ -408,7 +417,7 @@ class FeaturePipeline:
         shape = (T,) + tuple(sample.shape[1:])
         eng = self.model.engine() if hasattr(self.model, "engine") else None
         for slot, carry in pats:
-            G = Span(B, carry)
+            G = Span(B, carry, self._ns)
             ent = self._graphs[(slot, shape, sample.dtype, bool(self.model.training), id(eng), G)] = dict(calls=0, graph=None)
             self._capture(slot, s, filler, shape, G, ent, eng)
 
@@ -448,7 +457,7 @@ class FeaturePipeline:
         packs = [pk for pk in (lookup_pack(f) if isinstance(f, (list, tuple)) else None for f in per_batch) if pk is not None]
         ent.update(graph=g, static_in=static_in, feats=feats, deferred=deferred, packs=packs,
                    # the graph holds raw addresses of the slot's buffers and of the engine's operands: both stay alive with it
-                   keep=(eng, eng.slot_state(slot) if hasattr(eng, "slot_state") else None))
+                   keep=(eng, eng.slot_state((self._ns, slot)) if hasattr(eng, "slot_state") else None))
         g.replay()
         return feats, deferred
 
@@ -478,7 +487,7 @@ class FeaturePipeline:
         T = sum(p.shape[0] for p in pieces)
         if not 0 <= carry < batch or (carry + T) // batch < 1:
             raise ValueError(f"span of {T} images with carry {carry} completes no batch of {batch}")
-        self._submit(pieces, Span(int(batch), int(carry)), (carry + T) // batch)
+        self._submit(pieces, Span(int(batch), int(carry), self._ns), (carry + T) // batch)
 
     def _submit(self, batches, G, nb: int) -> None:
         if self.free_slots() <= 0:

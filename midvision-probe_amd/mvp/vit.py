@@ -148,11 +148,33 @@ class ViTEngine:
         self._pos: Dict[Tuple[int, int], torch.Tensor] = {}
         self._packs: Dict[Tuple[int, int, int, int, int], PackedFeatures] = {}
         self._slot_outs: Dict[tuple, dict] = {}  # output maps of pipelined forwards, owned by the slot
-        self._carry: Dict[tuple, torch.Tensor] = {}  # (batch, gh, gw, taps) -> [taps, batch * N, C] tap-level rows of a batch cut by a span's end
+        self._ns_lru: List[int] = []  # pipeline namespaces, least recently used first (see _touch_namespace)
+        self._carry: Dict[tuple, torch.Tensor] = {}  # (stream, batch, gh, gw, taps) -> [taps, batch * N, C] tap-level rows of a batch cut by a span's end
         pipeline.publish()  # the split weights are read by forwards on any stream
 
     # ------------------------------------------------------------------ helpers
+    def _touch_namespace(self) -> None:
+        """Slot keys are (pipeline namespace, slot index): every FeaturePipeline owns its buffer sets, so two pipelines over this
+        backbone (a training loop suspended with forwards in flight, a validation pass) never write each other's.  A loop that builds
+        a new pipeline per epoch would otherwise pile the sets up: keep those of the two most recently used namespaces (a captured
+        graph holds on to its own slot's buffers whatever happens here)."""
+        slot = pipeline.current_slot()
+        ns = slot[0] if isinstance(slot, tuple) else None
+        if ns is None or (self._ns_lru and self._ns_lru[-1] == ns):
+            return
+        if ns in self._ns_lru:
+            self._ns_lru.remove(ns)
+        self._ns_lru.append(ns)
+        if len(self._ns_lru) > 2:
+            dead = set(self._ns_lru[:-2])
+            self._ns_lru = self._ns_lru[-2:]
+            gone = lambda k: isinstance(k[-1], tuple) and k[-1][0] in dead  # noqa: E731
+            self._ws = {k: v for k, v in self._ws.items() if not gone(k)}
+            self._packs = {k: v for k, v in self._packs.items() if not gone(k)}
+            self._slot_outs = {k: v for k, v in self._slot_outs.items() if not gone(k)}
+
     def _workspace(self, B: int, gh: int, gw: int, headroom: int = 0) -> dict:
+        self._touch_namespace()
         key = (B, gh, gw, pipeline.current_slot())
         ws = self._ws.get(key)
         if ws is not None and ws["headroom"] < headroom:
@@ -184,7 +206,7 @@ class ViTEngine:
         maps).  A captured hipGraph of that slot's forward holds their raw addresses: the pipeline keeps this list alive with the
         graph, because the engine itself drops the buffers of other resolutions when a new one arrives."""
         return ([v for k, v in self._ws.items() if k[-1] == slot] + [v for k, v in self._packs.items() if k[-1] == slot]
-                + [v for k, v in self._slot_outs.items() if k[-1] == slot] + list(self._pos.values()))
+                + [v for k, v in self._slot_outs.items() if k[-1] == slot] + list(self._pos.values()) + list(self._carry.values()))
 
     def pos_for(self, gh: int, gw: int, dim2: int, dim3: int) -> torch.Tensor:
         """Pos-embed for a gh x gw grid.  'dino': bicubic resize with the +0.1 scale nudge of
@@ -276,10 +298,13 @@ class ViTEngine:
             if G < 1:
                 raise lib.MvpError(f"span forward: {carry} + {Bt} images complete no batch of {B}")
             x_bn = ws["xfull"][(ws["headroom"] - carry) * N:]  # the complete batches: carried rows (copied per tap) + this span's rows
-            ckey = (B, gh, gw, len(list(layers)))
+            ckey = (span.stream, B, gh, gw, len(list(layers)))  # one store per image stream (pipeline): see pipeline.Span
             store = self._carry.get(ckey)
             if store is None:
-                self._carry.clear()
+                for k in [k for k in self._carry if k[0] == span.stream]:
+                    del self._carry[k]  # the stream changed shape: its old store has no reader left (captured graphs keep theirs alive)
+                for k in [k for k in self._carry if k[0] not in self._ns_lru]:
+                    del self._carry[k]  # (streams of pipelines whose buffer sets were dropped too: _touch_namespace)
                 store = self._carry[ckey] = torch.empty(len(list(layers)), B * N, C, dtype=torch.float32, device=self.device)
         else:
             if groups < 1 or Bt % groups:

@@ -493,6 +493,30 @@ def test_span_forwards_in_eval_mode_return_each_batchs_own_features(output):
             assert torch.equal(x, y)
 
 
+def test_two_span_pipelines_over_one_backbone_keep_their_carries_apart():
+    """A loop suspended in the middle of a cut batch (its first images' tap rows wait in the engine's carry store) while ANOTHER pipeline
+    over the same backbone runs span forwards of its own — a validation pass inside a training epoch: each image stream has its own
+    carry store (pipeline.Span.stream), so both get every batch's own features."""
+    from evals.models.dino import DINO
+    from mvp import backbone as bb
+    from mvp.pipeline import FeaturePipeline, pipelined_features
+
+    dev = torch.device("cuda:0")
+    model = DINO(return_multilayer=True, add_norm=True, weights=bb.random_vit_state_dict(seed=3)).to(dev).eval()
+    a, b = _batches(dev, 6), [{k: v.flip(0) * 0.5 for k, v in x.items()} for x in _batches(dev, 4)]
+    ref_a = [[t.clone() for t in model(x["image"])] for x in a]
+    ref_b = [[t.clone() for t in model(x["image"])] for x in b]
+    ga = pipelined_features(model, a, pipe=FeaturePipeline(model, 2, graphs=True, group=2, span=7))
+    got_a = [[t.clone() for t in next(ga)[1]] for _ in range(2)]  # spans of 7 + 7 images are in flight: batches 1 and 3 are cut
+    got_b = [[t.clone() for t in f] for _, f in pipelined_features(model, b, pipe=FeaturePipeline(model, 2, graphs=True, group=2, span=7))]
+    got_a += [[t.clone() for t in f] for _, f in ga]
+    assert len(got_a) == 6 and len(got_b) == 4
+    for got, ref in ((got_a, ref_a), (got_b, ref_b)):
+        for x, y in zip(got, ref):
+            for u, v in zip(x, y):
+                assert torch.equal(u, v)
+
+
 def test_default_span_of_the_timed_configuration():
     """B = 16 at 224^2 on ViT-B/16: 110 images per forward (21670 rows = 85 x 3 tiles of 256^2: one round of 256 CUs for the
     N = 768 GEMMs); 480x640 (1201 rows per image): single batches on three streams, as before (measured faster than 18-image spans)."""
