@@ -50,7 +50,7 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 4
+#define MVP_ABI_VERSION 5 /* 5: mvp_upconv3_fwd_gather, mvp_upconv3_grad_boxsum; mvp_gemm_pp accepts conv; depth-loss workspace grew (query mvp_depth_loss_workspace_bytes) */
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
 int mvp_sizeof(const char* struct_name); /* sizeof(<struct_name>) as compiled into the library, -1 if unknown: for bindings to self-check */
