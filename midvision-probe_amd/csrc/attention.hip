@@ -32,6 +32,20 @@
 
 namespace {
 
+// Diagnostic knobs (tools/attn_bench.py builds variants): MVP_ATT_PRIO 1 = s_setprio 1 around the two MFMA clusters of a tile (a wave in
+// its matrix phase is then not starved of issue slots by its SIMD partner's softmax VALU stream); MVP_ATT_STAGGER n = waves 4-7 of the
+// resident kernel sleep n x 64 cycles after every barrier (SIMD partners out of phase: one's MFMAs beside the other's VALU).
+#ifndef MVP_ATT_PRIO
+#define MVP_ATT_PRIO 0
+#endif
+#ifndef MVP_ATT_STAGGER
+#define MVP_ATT_STAGGER 0
+#endif
+#if MVP_ATT_PRIO
+#define ATT_PRIO(v) __builtin_amdgcn_s_setprio(v)
+#else
+#define ATT_PRIO(v)
+#endif
 #ifndef MVP_ATT_ABLATE
 #define MVP_ATT_ABLATE 0
 #endif
@@ -61,6 +75,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) s[t][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  ATT_PRIO(1);
 #pragma unroll
   for (int ks = 0; ks < (MVP_ATT_ABLATE == 3 ? 0 : 2); ++ks) {
     const int coff = (((ks << 2) + g) ^ (lane & 7)) << 4;
@@ -82,6 +97,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
         s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k_hi, st.q_hi[qt][ks], s[t][qt], 0, 0, 0);
     }
   }
+  ATT_PRIO(0);
   // ---------------- online softmax (q on the lane; keys on registers + lane groups)
   const int kbase = key0 + g * 4;
   bf16x8_t p_hi[2][2], p_lo[2][2];
@@ -129,6 +145,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
   }
   // ---------------- O^T += V^T . P^T
   const int tr_q = c16 >> 2, tr_p = lane & 3;
+  ATT_PRIO(1);
 #pragma unroll
   for (int ks = 0; ks < (MVP_ATT_ABLATE == 2 ? 0 : 2); ++ks) {
     if (LAST && 2 * ks >= nsub) continue;    // both 16-key sub-tiles of this half are padding (P = 0)
@@ -155,6 +172,7 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
         st.o_acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_hi, p_hi[qt][ks], st.o_acc[dt][qt], 0, 0, 0);
     }
   }
+  ATT_PRIO(0);
 }
 
 template <int SPLIT>
@@ -339,6 +357,7 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles 1.. landed (and the previous pair's stores have left)
     __syncthreads();
+    if (MVP_ATT_STAGGER && wave >= 4) __builtin_amdgcn_s_sleep(MVP_ATT_STAGGER);
     const int nbh = bh + gridDim.x;
     if (nbh < npair) {  // the next pair's first tile into the one free slot, its Q into registers: under this pair's remaining tiles
       stage_tile(nbh, 0, (s0 + nkt) % nslot);
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (active) attn_store<SPLIT>(st, p, rowbase, q0, h, lane);
     if (nbh < npair) __builtin_amdgcn_s_barrier();  // next pair: its tile 0 is resident for everybody; everybody is done with this pair's tiles
+    if (MVP_ATT_STAGGER && wave >= 4) __builtin_amdgcn_s_sleep(MVP_ATT_STAGGER);
   }
 }
 

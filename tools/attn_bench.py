@@ -36,6 +36,10 @@ def main():
         variants = {"full": build(0), "prev": build(0, src=prev, tag="_prev")}
         for n in os.environ.get("SGB", "").split():  # the interleave ratio of the streaming kernel's S(t+1) / softmax(t) block
             variants[f"sgb{n}"] = build(0, extra=f"-DMVP_ATT_SGB={n}")
+    if "--prio" in sys.argv:  # s_setprio around the MFMA clusters x stagger of waves 4-7 (MVP_ATT_PRIO / MVP_ATT_STAGGER)
+        variants = {"base": build(0)}
+        for pr, stg in ((1, 0), (0, 12), (0, 25), (1, 12), (1, 25), (1, 40)):
+            variants[f"prio{pr}_stag{stg}"] = build(0, extra=f"-DMVP_ATT_PRIO={pr} -DMVP_ATT_STAGGER={stg}")
     # (tried in round 3 and dropped: delaying waves 4-7 of the resident kernel by 8 .. 48 x 64 cycles so that SIMD partners run out of
     # phase — 77.8 us -> 77.6 .. 80.4 at B = 96, 16.7 -> 16.8 .. 17.1 at B = 16: nothing)
     dev = torch.device("cuda")
