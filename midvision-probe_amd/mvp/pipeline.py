@@ -273,6 +273,7 @@ class FeaturePipeline:
             depth = 1
         self.model, self.depth = model, depth
         self.group = None if group is None else max(1, int(group))  # resolved at the first submit (needs the batch shape)
+        self._group_arg, self._resolved_for = self.group, None
         if self.depth == 1:
             self.group = 1
         # images per span forward (module docstring, "Spans"): None = default_span when ``group`` is chosen automatically, else off
@@ -318,6 +319,7 @@ class FeaturePipeline:
         if self._span_resolved:
             return self.group
         self._span_resolved = True
+        self._resolved_for = (tuple(images.shape), images.dtype)
         auto = self.group is None
         depth_free = self._depth_arg is None and os.environ.get("MVP_INFLIGHT") is None
         B = images.shape[0]
@@ -349,6 +351,25 @@ class FeaturePipeline:
             self.chains = max(1, min(self.depth, self.chains))
             self.streams = self.streams[:self.chains] if self.depth > 1 else []
         return self.group
+
+    def rebind(self, images: torch.Tensor) -> None:
+        """A cached pipeline (pipelined_features keeps one per model and mode) meets batches of another shape: choose group / span /
+        slots again for that shape.  Only while nothing is in flight.  The graphs already captured stay (they are keyed by shape); the
+        new shape's span forwards run eagerly unless this pipeline has captured nothing yet."""
+        if self._resolved_for is None or self._resolved_for == (tuple(images.shape), images.dtype):
+            return
+        if self._queue or self._open:
+            raise RuntimeError("rebind() needs an empty pipeline")
+        depth = default_depth() if self._depth_arg is None else int(self._depth_arg)
+        if not getattr(self.model, "supports_pipelining", False):
+            depth = 1
+        self.depth, self.group = depth, (1 if depth == 1 else self._group_arg)
+        self.chains = max(1, min(depth, self._streams_arg))
+        while len(self.streams) < (self.chains if depth > 1 else 0):
+            self.streams.append(torch.cuda.Stream())
+        self.streams = self.streams[:self.chains] if depth > 1 else []
+        self.span, self.span_batch, self._span_resolved, self._n = 0, 0, False, 0
+        self.resolve_group(images)
 
     # ------------------------------------------------------------------ one forward on a slot's stream
     def _eager(self, slot: int, images: torch.Tensor, groups: int = 1):
@@ -586,15 +607,30 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
             # MVP_INFLIGHT and ranks rehearsing on one card are final; otherwise the pipeline picks its own default once it knows
             # whether the forwards are grouped (2 slots, DPT probe included) or single batches (4; 1 under a DPT probe)
             depth = hint if (os.environ.get("MVP_INFLIGHT") is not None or os.environ.get("MVP_FORCE_DEVICE") is not None) else None
-        pipe = FeaturePipeline(model, depth, group=group, ungrouped_depth=hint)
+        # One pipeline per (model, mode, shape of the request), kept on the model: every epoch's loop and every validation pass replay the
+        # graphs the first one captured (setting a pipeline's graphs up costs ~0.25 s: a tenth of an NYU-sized epoch at this throughput).
+        # A cached pipeline that is still in use (a loop suspended mid-epoch) is left alone: the caller gets a fresh one.
+        cache = model.__dict__.setdefault("_mvp_pipelines", {}) if hasattr(model, "__dict__") else {}
+        key = (bool(getattr(model, "training", False)), depth, group, hint)
+        pipe = cache.get(key)
+        if pipe is None or len(pipe) or pipe._open or getattr(pipe, "_lent", False):
+            pipe = FeaturePipeline(model, depth, group=group, ungrouped_depth=hint)
+            cache[key] = pipe
+        pipe._lent = True
+        lent = pipe
     elif len(pipe):
         raise RuntimeError("pipelined_features needs an empty pipeline")
+    else:
+        lent = None
     if hasattr(batches, "consumer_lag"):
         # mvp.prefetch.DevicePrefetcher recycles its device buffers (it sizes its pool when its first batch is pulled): this generator
         # holds up to depth x group batches before the caller has issued the probe step of the first of them (which reads that batch's
         # target; its image is read by the forward in flight).  The group size is not known before the first batch: its upper bound.
         # (a span forward also holds the batch it cuts)
-        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth * ((pipe.group or MAX_GROUP) + (1 if (pipe.span or pipe.group is None) else 0)) - 1)
+        g_hold = (pipe.group or MAX_GROUP) + (1 if (pipe.span or pipe.group is None) else 0)
+        if lent is not None and pipe._resolved_for is not None:
+            g_hold = max(g_hold, MAX_GROUP + 1)  # a cached pipeline may be re-shaped by this loader's first batch (rebind)
+        batches.consumer_lag = max(int(batches.consumer_lag), pipe.depth * g_hold - 1)
     it = iter(batches)
     pending = collections.deque()
     held = []  # a batch pulled from the iterator that did not fit the group being formed
@@ -652,12 +688,18 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
         pending.extend(done)
         return True
 
+    started = []
+
     def feed() -> bool:
         if cut:
             return feed_span()
         first = pull()
         if first is None:
             return False
+        if not started:  # a pipeline taken from the model's cache may have been shaped for other batches
+            started.append(True)
+            if lent is not None:
+                pipe.rebind(first[1])
         G = pipe.resolve_group(first[1])
         if pipe.span and first[1].shape[0] == pipe.span_batch:
             held.append(first)
@@ -685,3 +727,5 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
             yield b, pipe.next()
     finally:
         pipe.drain()
+        if lent is not None:
+            lent._lent = False  # (the model's cached pipeline is free for the next loop)

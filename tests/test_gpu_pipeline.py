@@ -517,6 +517,41 @@ def test_two_span_pipelines_over_one_backbone_keep_their_carries_apart():
                 assert torch.equal(u, v)
 
 
+def test_epochs_reuse_the_models_cached_pipeline_and_rebind_to_new_shapes():
+    """``pipelined_features(model, loader)`` without an explicit pipeline keeps ONE pipeline per model and mode (train / eval): the second
+    epoch replays the graphs the first one captured instead of capturing again, a validation pass in eval mode gets its own, and a loader
+    with another image size re-shapes the cached pipeline (``rebind``).  Every batch's features equal the plain forward's."""
+    from evals.models.dino import DINO
+    from mvp import backbone as bb
+    from mvp.pipeline import pipelined_features
+
+    dev = torch.device("cuda:0")
+    model = DINO(return_multilayer=True, add_norm=True, weights=bb.random_vit_state_dict(seed=3)).to(dev).eval()
+    bs = _batches(dev, 20, B=4, hw=(32, 48))  # 7 tokens per image: spans of 32 images would be whole batches -> groups of 8
+    ref = [[t.clone() for t in model(b["image"])] for b in bs]
+
+    def epoch(batches, refs):
+        got = [[t.clone() for t in f] for _, f in pipelined_features(model, batches)]
+        assert len(got) == len(refs)
+        for a, b in zip(got, refs):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+
+    epoch(bs, ref)
+    (pipe,) = model._mvp_pipelines.values()
+    assert pipe.depth == 2 and pipe.group > 1 and pipe.graphs
+    ngraphs, calls = len(pipe._graphs), sum(e["calls"] for e in pipe._graphs.values())
+    epoch(bs, ref)
+    assert list(model._mvp_pipelines.values()) == [pipe] and len(pipe._graphs) == ngraphs
+    assert sum(e["calls"] for e in pipe._graphs.values()) > calls  # replays, no new capture
+    big = _batches(dev, 5, B=4, hw=(64, 80))
+    epoch(big, [[t.clone() for t in model(b["image"])] for b in big])
+    assert list(model._mvp_pipelines.values()) == [pipe] and pipe._resolved_for[0] == (4, 3, 64, 80)
+    model.train()
+    n_train = sum(1 for _ in pipelined_features(model, bs[:3]))
+    assert n_train == 3 and len(model._mvp_pipelines) == 2
+
+
 def test_default_span_of_the_timed_configuration():
     """B = 16 at 224^2 on ViT-B/16: 110 images per forward (21670 rows = 85 x 3 tiles of 256^2: one round of 256 CUs for the
     N = 768 GEMMs); 480x640 (1201 rows per image): single batches on three streams, as before (measured faster than 18-image spans)."""
