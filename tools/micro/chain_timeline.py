@@ -18,7 +18,7 @@ from mvp.optim import FlatAdamW
 from mvp.pipeline import FeaturePipeline, freeze_gc, pipelined_features
 from mvp.train import train_depth_step
 
-G, depth, streams = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 6), (2, 2), (3, 1)))
+G, depth, streams, SPAN = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 6), (2, 2), (3, 1), (4, 0)))  # SPAN: images per span forward (0: whole-batch groups of G)
 dev = torch.device("cuda")
 B = 16
 model = DINO(return_multilayer=True, add_norm=True, weights=bb.random_vit_state_dict(seed=0)).to(dev)
@@ -29,7 +29,7 @@ loss_fn = DepthLoss()
 g = torch.Generator().manual_seed(0)
 batches = [(torch.randn(B, 3, 224, 224, generator=g).to(dev), (torch.rand(B, 1, 224, 224, generator=g) * 9.9 + 0.05).to(dev)) for _ in range(4)]
 freeze_gc()
-pipe = FeaturePipeline(model, depth, graphs=False, group=G, streams=streams)
+pipe = FeaturePipeline(model, depth, graphs=False, group=G, streams=streams, span=SPAN or None)
 
 
 def run(n):
@@ -53,7 +53,7 @@ t_lo = ev[len(ev) // 5][0]
 t_hi = ev[4 * len(ev) // 5][0]
 mid = [e for e in ev if t_lo <= e[0] <= t_hi]  # steady middle: groups 2-4 of 5
 span = t_hi - t_lo
-print(f"B={B} 224^2 bf16x3, {G} batches per frozen forward, depth {depth}, {streams} forward stream(s); {len(trace)} launches traced over {n} steps")
+print(f"B={B} 224^2 bf16x3, " + (f"spans of {SPAN} images" if SPAN else f"{G} batches") + f" per frozen forward, depth {depth}, {streams} forward stream(s); {len(trace)} launches traced over {n} steps")
 print(f"ms/step: {untraced:.3f} untraced, {traced:.3f} with an event pair around every launch")
 
 

@@ -32,5 +32,5 @@ mkdir -p $OUT/${TAG}_profiles && cp profiles/${TAG}_* $OUT/${TAG}_profiles/ 2>/d
 cp $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_profiles/${TAG}_default_bench_kernel_stats.csv || true
 cp $(find $OUT/${TAG}_serial_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_profiles/${TAG}_serial_kernel_stats.csv || true
 python3 tools/step_trace.py $(find $OUT/${TAG}_serial_stats -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_profiles/${TAG}_serial_step_trace.txt || true
-python3 tools/micro/chain_timeline.py 6 2 1 > $OUT/${TAG}_profiles/${TAG}_chain_timeline.txt 2>/dev/null || true
+python3 tools/micro/chain_timeline.py 7 2 1 110 > $OUT/${TAG}_profiles/${TAG}_chain_timeline.txt 2>/dev/null || true
 echo "profile passes done: $(ls $OUT/${TAG}_profiles | wc -l) files"
