@@ -41,6 +41,7 @@ import collections
 import contextlib
 import itertools
 import os
+import weakref
 from typing import Iterable, Iterator, Tuple
 
 import torch
@@ -593,6 +594,19 @@ def _extract(model, images):
     return extract_features(model, images)
 
 
+_PIPELINES = weakref.WeakKeyDictionary()  # model -> {(training, depth, group, hint): FeaturePipeline}
+_NO_CACHE: dict = {}  # stand-in for models that cannot be weakly referenced (nothing is kept)
+
+
+def cached_pipelines(model) -> dict:
+    """The pipelines ``pipelined_features`` keeps for ``model`` (created on demand; empty for objects that cannot be weakly referenced)."""
+    try:
+        return _PIPELINES.setdefault(model, {})
+    except TypeError:
+        _NO_CACHE.clear()
+        return _NO_CACHE
+
+
 def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None, probe=None, group: int = None,
                        pipe: "FeaturePipeline" = None) -> Iterator[Tuple[object, object]]:
     """Yield ``(batch, features)`` for every batch of ``batches`` with up to ``depth`` forwards in flight: the forwards of the next
@@ -607,14 +621,16 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
             # MVP_INFLIGHT and ranks rehearsing on one card are final; otherwise the pipeline picks its own default once it knows
             # whether the forwards are grouped (2 slots, DPT probe included) or single batches (4; 1 under a DPT probe)
             depth = hint if (os.environ.get("MVP_INFLIGHT") is not None or os.environ.get("MVP_FORCE_DEVICE") is not None) else None
-        # One pipeline per (model, mode, shape of the request), kept on the model: every epoch's loop and every validation pass replay the
+        # One pipeline per (model, mode, shape of the request), kept beside the model (a weak map: nothing is attached to the module, so
+        # deepcopy / pickling of the model are unaffected, and the pipelines go when the model goes): every epoch's loop and every validation pass replay the
         # graphs the first one captured (setting a pipeline's graphs up costs ~0.25 s: a tenth of an NYU-sized epoch at this throughput).
         # A cached pipeline that is still in use (a loop suspended mid-epoch) is left alone: the caller gets a fresh one.
-        cache = model.__dict__.setdefault("_mvp_pipelines", {}) if hasattr(model, "__dict__") else {}
+        cache = cached_pipelines(model)
         key = (bool(getattr(model, "training", False)), depth, group, hint)
         pipe = cache.get(key)
         if pipe is None or len(pipe) or pipe._open or getattr(pipe, "_lent", False):
-            pipe = FeaturePipeline(model, depth, group=group, ungrouped_depth=hint)
+            # (the cached pipeline refers to its model weakly: the map's values must not keep its keys alive)
+            pipe = FeaturePipeline(weakref.proxy(model) if cache is not _NO_CACHE else model, depth, group=group, ungrouped_depth=hint)
             cache[key] = pipe
         pipe._lent = True
         lent = pipe

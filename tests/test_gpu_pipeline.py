@@ -523,7 +523,7 @@ def test_epochs_reuse_the_models_cached_pipeline_and_rebind_to_new_shapes():
     with another image size re-shapes the cached pipeline (``rebind``).  Every batch's features equal the plain forward's."""
     from evals.models.dino import DINO
     from mvp import backbone as bb
-    from mvp.pipeline import pipelined_features
+    from mvp.pipeline import cached_pipelines, pipelined_features
 
     dev = torch.device("cuda:0")
     model = DINO(return_multilayer=True, add_norm=True, weights=bb.random_vit_state_dict(seed=3)).to(dev).eval()
@@ -538,18 +538,20 @@ def test_epochs_reuse_the_models_cached_pipeline_and_rebind_to_new_shapes():
                 assert torch.equal(x, y)
 
     epoch(bs, ref)
-    (pipe,) = model._mvp_pipelines.values()
+    (pipe,) = cached_pipelines(model).values()
     assert pipe.depth == 2 and pipe.group > 1 and pipe.graphs
     ngraphs, calls = len(pipe._graphs), sum(e["calls"] for e in pipe._graphs.values())
     epoch(bs, ref)
-    assert list(model._mvp_pipelines.values()) == [pipe] and len(pipe._graphs) == ngraphs
+    assert list(cached_pipelines(model).values()) == [pipe] and len(pipe._graphs) == ngraphs
     assert sum(e["calls"] for e in pipe._graphs.values()) > calls  # replays, no new capture
     big = _batches(dev, 5, B=4, hw=(64, 80))
     epoch(big, [[t.clone() for t in model(b["image"])] for b in big])
-    assert list(model._mvp_pipelines.values()) == [pipe] and pipe._resolved_for[0] == (4, 3, 64, 80)
+    assert list(cached_pipelines(model).values()) == [pipe] and pipe._resolved_for[0] == (4, 3, 64, 80)
     model.train()
     n_train = sum(1 for _ in pipelined_features(model, bs[:3]))
-    assert n_train == 3 and len(model._mvp_pipelines) == 2
+    import copy
+    assert n_train == 3 and len(cached_pipelines(model)) == 2
+    assert len(cached_pipelines(copy.deepcopy(model))) == 0  # nothing of the pipelines hangs on the module itself
 
 
 def test_default_span_of_the_timed_configuration():
