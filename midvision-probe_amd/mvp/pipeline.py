@@ -279,6 +279,7 @@ class FeaturePipeline:
             self.group = 1
         # images per span forward (module docstring, "Spans"): None = default_span when ``group`` is chosen automatically, else off
         self._ns = next(_NAMESPACES)
+        self._lent = False  # pipelined_features: this (cached) pipeline is driving a loop right now
         self._span_arg = span
         # depth to fall to when ``depth`` is None and the forwards turn out to be single batches (``default_depth(probe)``: a DPT probe
         # step gains from grouped forwards beside it, 762 -> 802 img/s, but loses to single-batch ones, 739-748 -> 699-723)
@@ -595,7 +596,7 @@ def _extract(model, images):
 
 
 _PIPELINES = weakref.WeakKeyDictionary()  # model -> {(training, depth, group, hint): FeaturePipeline}
-_NO_CACHE: dict = {}  # stand-in for models that cannot be weakly referenced (nothing is kept)
+_NO_CACHE: dict = {}  # what cached_pipelines returns for a model that cannot be weakly referenced: always empty, nothing is kept
 
 
 def cached_pipelines(model) -> dict:
@@ -603,7 +604,6 @@ def cached_pipelines(model) -> dict:
     try:
         return _PIPELINES.setdefault(model, {})
     except TypeError:
-        _NO_CACHE.clear()
         return _NO_CACHE
 
 
@@ -628,10 +628,12 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
         cache = cached_pipelines(model)
         key = (bool(getattr(model, "training", False)), depth, group, hint)
         pipe = cache.get(key)
-        if pipe is None or len(pipe) or pipe._open or getattr(pipe, "_lent", False):
+        if pipe is None or len(pipe) or pipe._open or pipe._lent:
             # (the cached pipeline refers to its model weakly: the map's values must not keep its keys alive)
-            pipe = FeaturePipeline(weakref.proxy(model) if cache is not _NO_CACHE else model, depth, group=group, ungrouped_depth=hint)
-            cache[key] = pipe
+            keep = cache is not _NO_CACHE
+            pipe = FeaturePipeline(weakref.proxy(model) if keep else model, depth, group=group, ungrouped_depth=hint)
+            if keep:
+                cache[key] = pipe
         pipe._lent = True
         lent = pipe
     elif len(pipe):
