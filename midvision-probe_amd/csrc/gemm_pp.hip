@@ -46,6 +46,12 @@
 #ifndef MVP_PP_STAMP
 #define MVP_PP_STAMP 0
 #endif
+// MVP_PP_PRIO (diagnostic A/B, tools/pp_bench.py --prio): 0 = s_setprio 1 / 0 around every MFMA cluster (the shipped form);
+// 1 = no per-cluster flips, ONE s_setprio 1 for the later-dispatched wave group (waves 4-7) before the main loop
+// (MI355X_MICROARCH.md "Two waves per SIMD", item 4); 2 = no priority instructions at all.
+#ifndef MVP_PP_PRIO
+#define MVP_PP_PRIO 0
+#endif
 #if MVP_PP_STAMP
 #define PP_STAMP(v) const uint64_t v = __builtin_amdgcn_s_memtime()
 #define PP_ACC(ph) \
@@ -208,7 +214,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { asm volatile("" ::"v"(a_hi[j])); asm volatile("" ::"v"(a_lo[j])); asm volatile("" ::"v"(w_hi[j])); asm volatile("" ::"v"(w_lo[j])); }
 #else
+#if MVP_PP_PRIO == 0
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -219,7 +227,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_hi[j], c, 0, 0, 0);
         acc[i][half * 4 + j] = c;
       }
+#if MVP_PP_PRIO == 0
     __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
   };
 
@@ -235,6 +245,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
+#if MVP_PP_PRIO == 1
+  if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
 
 #if MVP_PP_STAMP

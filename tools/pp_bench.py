@@ -171,6 +171,9 @@ def main():
     if "--ablate" in sys.argv:
         for n, nm in ((1, "no_mfma"), (2, "no_dma"), (3, "no_read")):
             extra[nm] = build_ablate(n)
+    if "--prio" in sys.argv:  # priority forms of the main loop (MVP_PP_PRIO): static priority for waves 4-7 / no priority instructions
+        extra["static_prio"] = build_ablate(1, "MVP_PP_PRIO", "prio")
+        extra["no_prio"] = build_ablate(2, "MVP_PP_PRIO", "prio")
     if "--epilogue-ab" in sys.argv:  # the generic epilogue (gemm_epilogue) instead of the wide one, same main loop
         extra["generic_epilogue"] = build_ablate(0, "MVP_PP_WIDE_EPILOGUE", "wide")
     for B in Bs:
