@@ -50,7 +50,8 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 5 /* 5: mvp_upconv3_fwd_gather, mvp_upconv3_grad_boxsum; mvp_gemm_pp accepts conv; depth-loss workspace grew (query mvp_depth_loss_workspace_bytes) */
+#define MVP_ABI_VERSION 6 /* 6: mvp_gemm_args.out_f16_col0, mvp_attention_args.v_format (both structs grew by one int at the end; zero = the ABI 5 behaviour)
+                             5: mvp_upconv3_fwd_gather, mvp_upconv3_grad_boxsum; mvp_gemm_pp accepts conv; depth-loss workspace grew (query mvp_depth_loss_workspace_bytes) */
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
 int mvp_sizeof(const char* struct_name); /* sizeof(<struct_name>) as compiled into the library, -1 if unknown: for bindings to self-check */
@@ -154,6 +155,12 @@ typedef struct {
    * [rows][N / 32][hi 32 | lo 32] with row stride ldob (2 * N when dense), out_lo is ignored, N % 32 == 0 — the A operand of a following
    * large-M GEMM (fc1 -> fc2).  Any kernel of mvp_gemm_bias_act_res writes it.                                                        */
   int out_pair_layout;
+  /* --- mixed 16-bit forms inside the bf16-pair output (ABI 6): out_f16_col0 > 0 (a multiple of 64, MVP_PREC_BF16X3, out_hi and a lo
+   * half required): columns >= out_f16_col0 are written as hi = fp16(v) (round to nearest even), lo = bf16(v - hi) instead of
+   * hi = bf16(v), lo = bf16(v - hi) — the V third of the fused qkv projection (out_f16_col0 = 2 * H * 64), which the attention
+   * kernel multiplies with probabilities held as ONE fp16 value (mvp_attention_args.v_format).  Same 2 + 2 bytes, same arrays and
+   * layouts; |v - hi - lo| <= 2^-20 |v|.  Every kernel of mvp_gemm_bias_act_res / mvp_gemm_pp writes it (not stream-K).        */
+  int out_f16_col0;
 } mvp_gemm_args;
 #define MVP_TILES_ALONE 0
 #define MVP_TILES_SHARED 1
@@ -206,7 +213,16 @@ typedef struct {
   int precision;
   int out_layout;   /* MVP_PAIR_SEPARATE, or MVP_PAIR_A_ILV32 (1): out_hi is ONE [B*N][H*2][hi 32 | lo 32] array with row stride ld_out
                        (>= 2 * H * 64), out_lo ignored — the A operand of the large-M proj GEMM (mvp_gemm_args.pair_layout)               */
+  int v_format;     /* MVP_PREC_BF16X3 only.  MVP_ATT_V_BF16_PAIR (0): V is a bf16 pair like Q and K; the probabilities are split into a bf16
+                       pair too and P.V runs three products (hi.hi + hi.lo + lo.hi).  MVP_ATT_V_F16 (1, ABI 6): the V third of qkv holds
+                       hi = fp16(v), lo = bf16(v - hi) (mvp_gemm_args.out_f16_col0); the probabilities are held as ONE fp16 value
+                       (+ its bf16 rounding for the lo product): P.V = v_hi.p on the f16 MFMA + v_lo.p on the bf16 MFMA — two products
+                       instead of three and no hi / lo split of P on the vector pipe (the kernel is VALU-bound); the online softmax
+                       rescales its running maximum only when it rises by more than 2^6.  Q.K^T keeps its three products either way.
+                       Relative error of the output: ~2^-12 per probability (random, averaged over the keys) instead of 2^-17.        */
 } mvp_attention_args;
+#define MVP_ATT_V_BF16_PAIR 0
+#define MVP_ATT_V_F16 1
 int mvp_attention_fwd(const mvp_attention_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------

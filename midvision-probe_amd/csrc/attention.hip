@@ -28,6 +28,14 @@
 // LDS destination is lane-linear).
 //
 // SPLIT == 3: Q/K/V/P are bf16 pairs, each product runs hi*hi + hi*lo + lo*hi.
+// VF16 (SPLIT == 3 only; mvp_attention_args.v_format == MVP_ATT_V_F16, round 4): the kernels are VALU-bound — per 64-key tile and wave
+// ~340 vector instructions against 96 MFMAs, 3 of the ~7 per score spent splitting the probability into a bf16 pair.  A probability
+// lies in [0, 2^6] and needs no exponent range: ONE fp16 value carries it to 2^-12 relative.  So the V third of qkv arrives as
+// hi = fp16(v), lo = bf16(v - hi) (written that way by the qkv GEMM's epilogue, mvp_gemm_args.out_f16_col0) and
+//   O^T += v_hi . p16 (v_mfma_f32_16x16x32_f16)  +  v_lo . bf16(p) (the bf16 MFMA; p's rounding to 8 bits meets a factor already 2^-12 small)
+// — two products instead of three, one conversion per product instead of the split.  (lo stays bf16: an fp16 lo of a small v would
+// be a denormal.)  The running maximum is then only an exponent offset, so it is moved — and O, l rescaled — only when a row's
+// maximum rises by more than 2^6 above it (always at a pair's first tile): probabilities stay below 2^6 = 64, far inside fp16.
 #include "mvp_common.h"
 
 namespace {
@@ -50,6 +58,8 @@ namespace {
 #define MVP_ATT_ABLATE 0
 #endif
 constexpr int TILE = 64 * 128;  // one 64-key x 64-d bf16 tile
+constexpr float ATT_DEFER = 6.0f;  // VF16: the running maximum moves only when a row's maximum rises by more than this (exp2 units)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
 template <int SPLIT>
 struct AttnState {
@@ -64,8 +74,9 @@ struct AttnState {
 // body is kept lean: raw v_exp_f32 (__builtin_amdgcn_exp2f: no denormal range fix-up, 5 instructions fewer per
 // element; probabilities below 2^-126 are zero either way) and the key-validity mask compiled only into the LAST
 // tile's instantiation.
-template <int SPLIT, bool LAST>
+template <int SPLIT, bool LAST, bool VF16 = false>
 __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, const char* vb, int key0, int N, float cs, int lane) {
+  static_assert(!VF16 || SPLIT == 3, "the fp16-probability form belongs to the bf16x3 mode");
   const int g = lane >> 4, c16 = lane & 15;
   // LAST tile: only the first nsub 16-key sub-tiles hold real keys (N = 197: 5 keys of the 4th tile -> nsub = 1); the
   // products of the all-padding sub-tiles are skipped (wave-uniform branches) and their probabilities set to zero.
@@ -100,9 +111,44 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
   ATT_PRIO(0);
   // ---------------- online softmax (q on the lane; keys on registers + lane groups)
   const int kbase = key0 + g * 4;
-  bf16x8_t p_hi[2][2], p_lo[2][2];
+  bf16x8_t p_hi[2][2], p_lo[2][2];  // VF16: p_lo = bf16(p) (the partner of v_lo), p_h = fp16(p)
+  f16x8_t p_h[2][2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
+    if (VF16 && MVP_ATT_ABLATE != 1) {
+      float tmax = -1e30f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (LAST) s[t][qt][j] = ((kbase + t * 16 + j) < N) ? s[t][qt][j] : -1e30f;
+          tmax = fmaxf(tmax, s[t][qt][j]);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      // move the running maximum only if some row of the wave needs it (wave-uniform branch; every lane of a row sees the same tmax)
+      if (__builtin_amdgcn_ballot_w64((tmax - st.m_run[qt]) * cs > ATT_DEFER) != 0) {
+        const float m_new = fmaxf(st.m_run[qt], tmax);
+        const float alpha = __builtin_amdgcn_exp2f((st.m_run[qt] - m_new) * cs);
+        st.m_run[qt] = m_new;
+        st.l_run[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) st.o_acc[dt][qt] *= alpha;
+      }
+      const float mc = st.m_run[qt] * cs;
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float pv = (LAST && t >= nsub) ? 0.f : __builtin_amdgcn_exp2f(s[t][qt][j] * cs - mc);
+          psum += pv;
+          p_h[qt][t >> 1][(t & 1) * 4 + j] = (_Float16)pv;
+          p_lo[qt][t >> 1][(t & 1) * 4 + j] = (__bf16)pv;
+        }
+      st.l_run[qt] += psum;
+      continue;
+    }
     if (MVP_ATT_ABLATE == 1) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -157,6 +203,18 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
       const bf16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(vb + off));
       const bf16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(vb + off + 16 * 128));
       const bf16x8_t v_hi = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      if (VF16) {  // v_hi holds fp16 bits, v_lo bf16: O^T += v_hi . p16 + v_lo . bf16(p)
+        const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(vb + TILE + off));
+        const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(vb + TILE + off + 16 * 128));
+        const bf16x8_t v_lo = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const f16x8_t v_h = __builtin_bit_cast(f16x8_t, v_hi);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          st.o_acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v_lo, p_lo[qt][ks], st.o_acc[dt][qt], 0, 0, 0);
+          st.o_acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v_h, p_h[qt][ks], st.o_acc[dt][qt], 0, 0, 0);
+        }
+        continue;
+      }
       if (SPLIT == 3) {
         const bf16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(vb + TILE + off));
         const bf16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(vb + TILE + off + 16 * 128));
@@ -244,7 +302,7 @@ __device__ __forceinline__ void attn_stage_piece(const mvp_attention_args& p, si
   }
 }
 
-template <int SPLIT>
+template <int SPLIT, bool VF16 = false>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attention_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
@@ -271,8 +329,8 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attenti
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     if (active) {
       const char* kb = smem + (kt & 1) * STAGE;
-      if (kt == nkt - 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
-      else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+      if (kt == nkt - 1) attn_tile<SPLIT, true, VF16>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+      else attn_tile<SPLIT, false, VF16>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -291,7 +349,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attenti
 //   i+1's slot 0, and pair i+1's tiles t >= 1 fall into slots pair i has finished with when the pair-boundary barrier is passed.
 // Per pair: [tile 0 resident, Q in registers] -> issue tiles 1.. (land under tile 0's compute) -> tile 0 -> vmcnt(0) + barrier ->
 // issue next pair's tile 0 + Q -> tiles 1.. -> vmcnt(0) (the prefetch, issued long before) -> output stores -> barrier.
-template <int SPLIT>
+template <int SPLIT, bool VF16 = false>
 __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_attention_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
@@ -352,8 +410,8 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
     st.l_run[0] = st.l_run[1] = 0.f;
     if (active && MVP_ATT_ABLATE != 5) {
       const char* kb = smem + s0 * STAGE;
-      if (nkt == 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, 0, p.N, cs, lane);
-      else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, 0, p.N, cs, lane);
+      if (nkt == 1) attn_tile<SPLIT, true, VF16>(st, kb, kb + NARR * TILE, 0, p.N, cs, lane);
+      else attn_tile<SPLIT, false, VF16>(st, kb, kb + NARR * TILE, 0, p.N, cs, lane);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles 1.. landed (and the previous pair's stores have left)
     __syncthreads();
@@ -366,8 +424,8 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
     if (active) {
       for (int kt = 1; kt < (MVP_ATT_ABLATE == 5 ? 0 : nkt); ++kt) {
         const char* kb = smem + ((s0 + kt) % nslot) * STAGE;
-        if (kt == nkt - 1) attn_tile<SPLIT, true>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
-        else attn_tile<SPLIT, false>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+        if (kt == nkt - 1) attn_tile<SPLIT, true, VF16>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
+        else attn_tile<SPLIT, false, VF16>(st, kb, kb + NARR * TILE, kt * 64, p.N, cs, lane);
       }
     }
     // The prefetch was issued a whole pair's worth of tiles ago: this wait is free.  It comes BEFORE the output stores on purpose —
@@ -380,14 +438,14 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
   }
 }
 
-template <int SPLIT>
+template <int SPLIT, bool VF16 = false>
 int launch_attention(const mvp_attention_args* a, hipStream_t s) {
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int STAGE = 2 * NARR * TILE;
   constexpr int SMEM_STREAM = 2 * STAGE, SMEM_RES = 5 * STAGE;  // resident kernel: ring of nkt + 1 <= 5 tile slots (160 KiB at bf16x3)
   static int configured = [] {
-    int e = (int)hipFuncSetAttribute((const void*)attention_stream_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_STREAM);
-    if (e == 0) e = (int)hipFuncSetAttribute((const void*)attention_resident_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_RES);
+    int e = (int)hipFuncSetAttribute((const void*)attention_stream_kernel<SPLIT, VF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_STREAM);
+    if (e == 0) e = (int)hipFuncSetAttribute((const void*)attention_resident_kernel<SPLIT, VF16>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_RES);
     return e;
   }();
   if (configured != 0) return MVP_ELAUNCH;
@@ -401,10 +459,10 @@ int launch_attention(const mvp_attention_args* a, hipStream_t s) {
     }();
     const int per_cu = (160 * 1024) / ((nkt + 1) * STAGE) > 0 ? (160 * 1024) / ((nkt + 1) * STAGE) : 1;
     const int grid = a->B * a->H < cus * per_cu ? a->B * a->H : cus * per_cu;
-    hipLaunchKernelGGL((attention_resident_kernel<SPLIT>), dim3(grid), dim3(512), (nkt + 1) * STAGE, s, *a);
+    hipLaunchKernelGGL((attention_resident_kernel<SPLIT, VF16>), dim3(grid), dim3(512), (nkt + 1) * STAGE, s, *a);
   } else {
     dim3 grid((a->N + 127) / 128, a->B * a->H);
-    hipLaunchKernelGGL((attention_stream_kernel<SPLIT>), grid, dim3(256), SMEM_STREAM, s, *a);
+    hipLaunchKernelGGL((attention_stream_kernel<SPLIT, VF16>), grid, dim3(256), SMEM_STREAM, s, *a);
   }
   MVP_LAUNCH_CHECK();
   return MVP_OK;
@@ -419,8 +477,10 @@ extern "C" int mvp_attention_fwd(const mvp_attention_args* a, void* stream) {
   if (a->out_layout != MVP_PAIR_SEPARATE && (a->out_layout != MVP_PAIR_A_ILV32 || a->precision != MVP_PREC_BF16X3 || a->ld_out < 2 * a->H * 64)) return MVP_EINVAL;
   if (a->precision == MVP_PREC_BF16X3) {
     if (!a->qkv_lo || (!a->out_lo && a->out_layout == MVP_PAIR_SEPARATE)) return MVP_EINVAL;
+    if (a->v_format == MVP_ATT_V_F16) return launch_attention<3, true>(a, (hipStream_t)stream);
+    if (a->v_format != MVP_ATT_V_BF16_PAIR) return MVP_EINVAL;
     return launch_attention<3>(a, (hipStream_t)stream);
   }
-  if (a->precision != MVP_PREC_BF16) return MVP_EINVAL;
+  if (a->precision != MVP_PREC_BF16 || a->v_format != MVP_ATT_V_BF16_PAIR) return MVP_EINVAL;
   return launch_attention<1>(a, (hipStream_t)stream);
 }

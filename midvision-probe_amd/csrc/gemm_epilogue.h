@@ -62,8 +62,9 @@ __device__ __forceinline__ void region_tile(int L, int TM, int TN, int M, int N,
 // Fused epilogue.  acc[i][j] = 16x16 accumulator of n-fragment i, m-fragment j of this wave's WM x WN output tile (MFMA issued
 // "swapped": a lane's 4 registers are 4 consecutive output columns of row lane & 15).  smem = the kernel's dynamic LDS (>= NW * 32 *
 // (WN + 4) * 4 bytes), free for reuse.  (m0, n0) = the workgroup's tile origin, (wm0, wn0) = this wave's offset inside it.
-template <int NT, int MT, int WN, bool EXT>
-__device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
+// ARGS: mvp_gemm_args, or the same struct read in place from the kernel-argument segment (address space 4; gemm_pp.hip's tile loop).
+template <int NT, int MT, int WN, bool EXT, class ARGS>
+__device__ __forceinline__ void gemm_epilogue(const ARGS& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
                                               const int m0, const int n0, const int wm0, const int wn0) {
   const int frow = lane & 15;
   const int fq = lane >> 4;
@@ -101,12 +102,11 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
       for (int i = 0; i < NT; ++i)
         *(f32x4_t*)(ep + (jj * 16 + frow) * EPW + i * 16 + fq * 4) = acc[i][h * 2 + jj];
     // phase 2: row-contiguous read-back, fused bias / activation / residual, full-line stores
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
+    auto rows = [&](const int it) {
       const int lr = it * RPI + er;
       const int m = m0 + wm0 + h * 32 + lr;
       const f32x4_t a4 = *(const f32x4_t*)(ep + lr * EPW + ec);
-      if (m >= p.M || ncol >= p.N) continue;
+      if (m >= p.M || ncol >= p.N) return;
       int orow = m;
       if (p.row_group > 0) {
         const int gidx = m / p.row_group;
@@ -188,8 +188,13 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
           for (int e = 0; e < 4; ++e) v[e] *= keep[e];  // (out_f32 above stayed un-gated)
         }
         uint32_t h01, l01, h23, l23;
-        split2_bf16(v[0], v[1], h01, l01);
-        split2_bf16(v[2], v[3], h23, l23);
+        if (p.out_f16_col0 > 0 && ncol >= p.out_f16_col0) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv (4 columns: all in or all out)
+          split2_f16_bf16(v[0], v[1], h01, l01);
+          split2_f16_bf16(v[2], v[3], h23, l23);
+        } else {
+          split2_bf16(v[0], v[1], h01, l01);
+          split2_bf16(v[2], v[3], h23, l23);
+        }
         const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;  // one array, hi | lo interleaved per 32 columns (N % 32 == 0: host check)
         const size_t o = (size_t)orow * p.ldob + (oilv ? ilv32_col(ncol) : ncol);
         if (oilv) {
@@ -210,6 +215,17 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
             }
         }
       }
+    };
+    // The `h` loop MUST be unrolled (acc[][h * 2 + jj] is a register array: a dynamic index sends all 128 accumulators through
+    // scratch — 528 bytes per lane in the EXT instantiations of round 3, where the fully unrolled body exceeded the pragma-unroll
+    // size limit and the compiler silently kept `h` as a loop).  The row loop only moves LDS / global addresses: with the large EXT body
+    // it stays a loop, which keeps the unrolled size under the limit.
+    if constexpr (EXT) {
+#pragma nounroll
+      for (int it = 0; it < 32 / RPI; ++it) rows(it);
+    } else {
+#pragma unroll
+      for (int it = 0; it < 32 / RPI; ++it) rows(it);
     }
   }
 }
@@ -217,115 +233,152 @@ __device__ __forceinline__ void gemm_epilogue(const mvp_gemm_args& p, f32x4_t (&
 // Wide epilogue of the large-M kernel (gemm_pp.hip) for the combinations the ViT blocks use — compiled per combination, no runtime
 // feature branches.  Same arithmetic as gemm_epilogue() (bias, erf-GELU, fp32 residual, fp32 and / or bf16-pair output, row remap),
 // hence the same bits, but shaped for the memory system, which is what bounds it: when every CU of a round reaches its epilogue at
-// once, 58-232 MB leave the chip in one burst, and that burst ran at 2.8-3.5 TB/s against the 6.9 TB/s a plain fill reaches
-// (in-kernel stamps: 27 % of the qkv GEMM, 20 % of fc2).  What it changes:
+// once, 58-232 MB leave the chip in one burst.  What it does about it:
 //   * a lane owns 8 consecutive columns (two b128 reads of the per-wave LDS scratch): every store is 16 bytes per lane — the pair
 //     halves left as 8-byte stores before, which run at 0.5-0.7x the 16-byte rate on gfx950;
-//   * the residual rows of the NEXT 32-row chunk are loaded before the stores of the current one are issued: vmcnt retires in issue
-//     order, so a residual load issued behind a store waits for that store's whole round trip (the generic loop did that once per
-//     row group: a dependent load -> store -> load chain).
-// N % 8 == 0 and 16-byte-aligned rows are required (the caller checks and falls back to gemm_epilogue()).
+//   * the residual rows of the NEXT 16-row unit are loaded before the stores of the current one are issued: vmcnt retires in issue
+//     order, so a residual load issued behind a store waits for that store's whole round trip;
+//   * (round 4) NO BRANCHES: every global access is a buffer instruction whose per-lane offset is the out-of-range sentinel for rows
+//     past M / columns past N (loads return zeros, stores are dropped), absent operands (no bias, no lo array) are zero-sized
+//     resources.  With `if (row < M) { load / add / store }` the compiler sinks the uses of the loaded bias / residual registers into the
+//     conditional region, and its wait-count pass — which must assume the skipped path leaves those loads pending — then emits a full
+//     s_waitcnt vmcnt(0) in EVERY 16-row unit: each unit waited for the previous unit's stores to be acknowledged (8 store round trips
+//     per tile = the 16 k cycles the round-3 stamps show for the qkv epilogue), and, once the tile loop put the main loop behind the
+//     epilogue, the same "maybe pending" registers cost a vmcnt(0) per k-step in the main loop.  Straight-line code gets counted waits.
+//     A fixed instruction count per tile (2 bias loads, 4 stores per unit, 4 residual / 2 gate loads per unit) also lets the caller
+//     count the epilogue's operations in its own vmcnt arithmetic (gemm_pp.hip, tile switch).
+// N % 8 == 0, 16-byte-aligned rows and arrays below 2 GiB are required (gemm_epilogue_wide_variant() checks; else gemm_epilogue()).
 // GATE: the backward of a ReLU fused into an input-gradient GEMM (mask_mode 2: v *= the stored byte gate; the DPT probe's
 // out_conv[2] input gradient, 200 704 x 512 outputs) — the 8 gate bytes of a lane are one 8-byte load, prefetched like the residual.
-template <int NT, int MT, int WN, int ACT, bool RES, bool F32OUT, bool PAIR, bool GATE = false>
-__device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
-                                                   const int m0, const int n0, const int wm0, const int wn0) {
-  static_assert(WN == 64 && NT == 4 && (MT % 2) == 0, "wave tile 32k x 64");
+// LDS scratch: 16 rows x (WN + 4) floats per wave (4352 B; 34 KB for the 8 waves) at `smem` — the persistent large-M kernel points it at
+// its second k-step buffer while the first already receives the next tile's operands.
+// `after_first_loads()` is called once the bias (and first residual / gate) loads are issued and before anything waits for them: the
+// caller's hook for memory operations that must be OLDER than the epilogue's stores but need not delay its first loads (the next
+// tile's LDS-DMA prefetch).
+// Memory operations issued per wave, for the caller's vmcnt arithmetic: 2 bias loads, then per 16-row unit 4 stores (+ 4 residual
+// loads, or 2 gate loads, for the units after the first, issued one unit ahead).
+template <bool RES, bool GATE>
+struct gemm_epilogue_wide_ops {
+  static constexpr int before_hook = 2 + (RES ? 4 : 0) + (GATE ? 2 : 0);              // bias, unit 0's residual / gate rows
+  static constexpr int after_hook = 8 * 4 + 7 * ((RES ? 4 : 0) + (GATE ? 2 : 0));     // 32 stores, the other units' residual / gate rows
+};
+template <int NT, int MT, int WN, int ACT, bool RES, bool F32OUT, bool PAIR, bool GATE = false, class ARGS = mvp_gemm_args, class HOOK>
+__device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
+                                                   const int m0, const int n0, const int wm0, const int wn0, HOOK&& after_first_loads) {
+  static_assert(WN == 64 && NT == 4 && MT == 8, "wave tile 128 x 64");
+  static_assert(F32OUT != PAIR, "one output form per instantiation (4 stores per unit)");
   constexpr int EPW = WN + 4;                 // padded scratch row, floats
-  constexpr int EP_BYTES = 32 * EPW * 4;      // per wave
+  constexpr int EP_BYTES = 16 * EPW * 4;      // per wave
+  constexpr int SENT = 0x7fffff00;            // out-of-range byte offset (every resource below has at most that many bytes)
   const int frow = lane & 15, fq = lane >> 4;
   float* ep = (float*)(smem + wave * EP_BYTES);
   const int er = lane >> 3, ec = (lane & 7) * 8;
   const int ncol = n0 + wn0 + ec;
   const bool col_ok = ncol < p.N;  // (N % 8 == 0: the 8 columns are all in or all out)
-  float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (p.bias && col_ok) {
-    const float4 b0 = *(const float4*)(p.bias + ncol), b1 = *(const float4*)(p.bias + ncol + 4);
-    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-  }
+  auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, ptr ? SENT : 0, 0x00020000); };  // null: every access out of range
+  const __amdgpu_buffer_rsrc_t r_bias = rsrc(p.bias), r_res = rsrc(RES ? (const void*)p.residual : nullptr), r_gate = rsrc(GATE ? (const void*)p.relu_mask : nullptr);
+  const __amdgpu_buffer_rsrc_t r_o32 = rsrc(F32OUT ? (const void*)p.out_f32 : nullptr), r_ohi = rsrc(PAIR ? (const void*)p.out_hi : nullptr);
   const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;
-  auto out_row = [&](int m) {
-    if (p.row_group <= 0) return m;
-    const int gidx = m / p.row_group;
-    return gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
+  const bool f16_cols = PAIR && p.out_f16_col0 > 0 && (n0 + wn0) >= p.out_f16_col0;  // this wave's 64 columns take the fp16-hi form
+  const __amdgpu_buffer_rsrc_t r_olo = rsrc(PAIR ? (oilv ? (const void*)p.out_hi : (const void*)p.out_lo) : nullptr);  // interleaved: the lo half sits 64 bytes behind the hi half
+  const int lo_soff = oilv ? 64 : 0;
+  const int ob = col_ok ? ncol * 4 : SENT;
+  const u32x4_t bias_a = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 0, 0), bias_b = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 16, 0);
+  // row m of the tile -> byte offsets into the output / residual / gate arrays (the sentinel for rows past M and columns past N)
+  const int pcol = PAIR ? (oilv ? ilv32_col(ncol) : ncol) : 0;
+  struct row_off { int out, res, gate; };
+  auto offsets = [&](int m) {
+    row_off o;
+    const bool ok = (m < p.M) && col_ok;
+    int orow = m;
+    if (p.row_group > 0) {  // (wave-uniform: the patch embedding's output-row remap)
+      const int gidx = m / p.row_group;
+      orow = gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
+    }
+    o.out = ok ? (F32OUT ? (orow * p.ldo + ncol) * 4 : (orow * p.ldob + pcol) * 2) : SENT;
+    o.res = SENT; o.gate = SENT;
+    if (RES) {
+      const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : orow;
+      o.res = ok ? (rrow * p.ldr + ncol) * 4 : SENT;
+    }
+    if (GATE) o.gate = ok ? (orow * p.ldm + ncol) : SENT;
+    return o;
   };
   // Work unit = 16 rows (2 wave-instructions of 8 rows): small enough that the kernel's register allocation stays where the main loop
-  // put it (the whole 32-row chunk in flight cost 40 more VGPRs: 255, i.e. no other wave can share the SIMDs with this kernel's two —
+  // put it (a whole 32-row chunk in flight cost 40 more VGPRs: no other wave could then share the SIMDs with this kernel's two —
   // the probe step's small kernels run beside the frozen forward and need that room).
   constexpr int HIT = 2;
-  float4 rpre[HIT][2];
-  uint64_t gpre[HIT];
-  auto load_res = [&](int u) {  // residual rows (and gate bytes) of 16-row unit u (u = 0 .. MT - 1)
+  u32x4_t rpre[HIT][2];
+  u32x2_t gpre[HIT];
+  row_off ro[HIT], ro_next[HIT];
+  auto load_res = [&](int u) {  // offsets of 16-row unit u, and its residual rows / gate bytes
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
-      const int m = m0 + wm0 + u * 16 + it * 8 + er;
-      if (GATE) gpre[it] = (m < p.M && col_ok) ? *(const uint64_t*)(p.relu_mask + (size_t)out_row(m) * p.ldm + ncol) : 0ull;
-      if (!RES) continue;
-      rpre[it][0] = rpre[it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.M && col_ok) {
-        const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : out_row(m);
-        const float* rp = p.residual + (size_t)rrow * p.ldr + ncol;
-        rpre[it][0] = *(const float4*)rp;
-        rpre[it][1] = *(const float4*)(rp + 4);
+      ro_next[it] = offsets(m0 + wm0 + u * 16 + it * 8 + er);
+      if (GATE) gpre[it] = __builtin_amdgcn_raw_buffer_load_b64(r_gate, ro_next[it].gate, 0, 0);
+      if (RES) {
+        rpre[it][0] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 0, 0);
+        rpre[it][1] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 16, 0);
       }
     }
   };
-  if (RES || GATE) load_res(0);
+  load_res(0);
+  after_first_loads();
+  float bias8[8];
 #pragma unroll
-  for (int h = 0; h < MT / 2; ++h) {
-    // accumulators -> LDS (lane: row frow of the m-fragment, columns i*16 + 4*fq ..)
+  for (int e = 0; e < 4; ++e) { bias8[e] = __builtin_bit_cast(float, bias_a[e]); bias8[4 + e] = __builtin_bit_cast(float, bias_b[e]); }
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+  for (int u = 0; u < MT; ++u) {
+    // (straight-line code: without the fence the scheduler pulls the LDS round trips and residual loads of later units forward until
+    // the register file is full — 256 VGPRs and spills)
+    __builtin_amdgcn_sched_barrier(0);
+    // accumulators of m-fragment u -> LDS (lane: row frow of the m-fragment, columns i*16 + 4*fq ..)
 #pragma unroll
-      for (int i = 0; i < NT; ++i) *(f32x4_t*)(ep + (jj * 16 + frow) * EPW + i * 16 + fq * 4) = acc[i][h * 2 + jj];
+    for (int i = 0; i < NT; ++i) *(f32x4_t*)(ep + frow * EPW + i * 16 + fq * 4) = acc[i][u];
+    float v[HIT][8];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int u = h * 2 + hh;
-      float v[HIT][8];
+    for (int it = 0; it < HIT; ++it) {
+      ro[it] = ro_next[it];
+      const int lr = it * 8 + er;
+      const f32x4_t a = *(const f32x4_t*)(ep + lr * EPW + ec), b = *(const f32x4_t*)(ep + lr * EPW + ec + 4);
 #pragma unroll
-      for (int it = 0; it < HIT; ++it) {
-        const int lr = hh * 16 + it * 8 + er;
-        const f32x4_t a = *(const f32x4_t*)(ep + lr * EPW + ec), b = *(const f32x4_t*)(ep + lr * EPW + ec + 4);
+      for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + bias8[e]; v[it][4 + e] = b[e] + bias8[4 + e]; }
+      if (ACT == MVP_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + bias8[e]; v[it][4 + e] = b[e] + bias8[4 + e]; }
-        if (ACT == MVP_ACT_GELU) {
+        for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
+      }
+      if (GATE) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
-        }
-        if (GATE) {
+        for (int e = 0; e < 8; ++e) v[it][e] *= ((gpre[it][e >> 2] >> (8 * (e & 3))) & 0xffu) ? 1.f : 0.f;
+      }
+      if (RES) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[it][e] *= ((gpre[it] >> (8 * e)) & 0xffull) ? 1.f : 0.f;
-        }
-        if (RES) {
-          v[it][0] += rpre[it][0].x; v[it][1] += rpre[it][0].y; v[it][2] += rpre[it][0].z; v[it][3] += rpre[it][0].w;
-          v[it][4] += rpre[it][1].x; v[it][5] += rpre[it][1].y; v[it][6] += rpre[it][1].z; v[it][7] += rpre[it][1].w;
+        for (int e = 0; e < 4; ++e) {
+          v[it][e] += __builtin_bit_cast(float, rpre[it][0][e]);
+          v[it][4 + e] += __builtin_bit_cast(float, rpre[it][1][e]);
         }
       }
-      if ((RES || GATE) && u + 1 < MT) load_res(u + 1);  // issued BEFORE this unit's stores: its data never waits behind them
+    }
+    if (u + 1 < MT) load_res(u + 1);  // issued BEFORE this unit's stores: its data never waits behind them
 #pragma unroll
-      for (int it = 0; it < HIT; ++it) {
-        const int m = m0 + wm0 + u * 16 + it * 8 + er;
-        if (m >= p.M || !col_ok) continue;
-        const int orow = out_row(m);
-        if (F32OUT) {
-          float* op = p.out_f32 + (size_t)orow * p.ldo + ncol;
-          *(float4*)op = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-          *(float4*)(op + 4) = make_float4(v[it][4], v[it][5], v[it][6], v[it][7]);
-        }
-        if (PAIR) {
-          uint32_t hw[4], lw[4];
+    for (int it = 0; it < HIT; ++it) {
+      if (F32OUT) {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, v[it][0]), __builtin_bit_cast(uint32_t, v[it][1]),
+                                                       __builtin_bit_cast(uint32_t, v[it][2]), __builtin_bit_cast(uint32_t, v[it][3])}, r_o32, ro[it].out, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, v[it][4]), __builtin_bit_cast(uint32_t, v[it][5]),
+                                                       __builtin_bit_cast(uint32_t, v[it][6]), __builtin_bit_cast(uint32_t, v[it][7])}, r_o32, ro[it].out, 16, 0);
+      }
+      if (PAIR) {
+        uint32_t hw[4], lw[4];
+        if (f16_cols) {  // (wave-uniform: out_f16_col0 % 64 == 0)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
-          if (oilv) {
-            mvp_bf16* o = p.out_hi + (size_t)orow * p.ldob + ilv32_col(ncol);
-            *(u32x4_t*)o = u32x4_t{hw[0], hw[1], hw[2], hw[3]};
-            *(u32x4_t*)(o + 32) = u32x4_t{lw[0], lw[1], lw[2], lw[3]};
-          } else {
-            const size_t o = (size_t)orow * p.ldob + ncol;
-            *(u32x4_t*)(p.out_hi + o) = u32x4_t{hw[0], hw[1], hw[2], hw[3]};
-            if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{lw[0], lw[1], lw[2], lw[3]};
-          }
         }
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].out, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].out, lo_soff, 0);
       }
     }
   }
@@ -333,6 +386,15 @@ __device__ __forceinline__ void gemm_epilogue_wide(const mvp_gemm_args& p, f32x4
 
 // Which wide-epilogue instantiation serves these arguments (0 = none: the generic epilogue).
 __host__ __device__ __forceinline__ int gemm_epilogue_wide_variant(const mvp_gemm_args& p) {
+  {  // the wide epilogues address every array through a buffer resource with 32-bit byte offsets: all of them below 2 GiB
+    const int64_t lim = 0x7fffff00ll;
+    const int64_t rows = p.row_group > 0 ? ((int64_t)(p.M - 1) / p.row_group) * p.row_group_stride + p.row_group_off + p.row_group : p.M;
+    if (p.out_f32 && rows * p.ldo * 4 > lim) return 0;
+    if (p.out_hi && rows * p.ldob * 2 + 64 > lim) return 0;
+    if (p.residual && (p.res_row_mod > 0 ? (int64_t)p.res_row_mod : rows) * p.ldr * 4 > lim) return 0;
+    if (p.relu_mask && rows * p.ldm > lim) return 0;
+    if ((int64_t)p.N * 4 > lim) return 0;
+  }
   if (p.relu_mask && p.mask_mode == 2 && !p.out_mask && !p.residual2 && !p.act_after_res && !p.residual_hi && !p.residual && p.act == MVP_ACT_NONE &&
       p.out_f32 && !p.out_hi && !(p.N & 7) && !(p.ldm & 7) && !((size_t)p.relu_mask & 7) && !(p.ldo & 3) && !((size_t)p.out_f32 & 15) &&
       !(p.bias && ((size_t)p.bias & 15)))

@@ -52,6 +52,16 @@
 #ifndef MVP_PP_PRIO
 #define MVP_PP_PRIO 0
 #endif
+// MVP_PP_PREFETCH 0 (diagnostic build): persistent over tiles, but every tile runs the cold prologue after the previous epilogue.
+#ifndef MVP_PP_PREFETCH
+#define MVP_PP_PREFETCH 1
+#endif
+#ifndef MVP_PP_RELAXED
+#define MVP_PP_RELAXED 1  // 0 (diagnostic build): the first phase of a prefetched tile waits with the steady-state count (all stores acknowledged)
+#endif
+#ifndef MVP_PP_NOLOOP
+#define MVP_PP_NOLOOP 0  // 1 (diagnostic build): one tile per workgroup, no tile loop in the code at all
+#endif
 #if MVP_PP_STAMP
 #define PP_STAMP(v) const uint64_t v = __builtin_amdgcn_s_memtime()
 #define PP_ACC(ph) \
@@ -72,6 +82,19 @@ constexpr int PP_SMEM = 2 * PP_BUF_B;    // two k-step buffers = 128 KiB
 
 // CONV (separate hi / lo arrays only): the A operand is the implicit im2col of a channels-last activation, exactly gemm.hip's conv mode
 // (K index = tap * C + c, a 32-deep k-step never straddles a tap: C % 32 == 0; padding taps are read as buffer-out-of-range zeros).
+//
+// Persistent over tiles (round 4).  The grid is min(tiles, CUs) workgroups; workgroup b runs tiles b, b + grid, b + 2 grid, ... — the
+// tile a freshly dispatched workgroup of the one-tile-per-workgroup launch would have got in that round, so the XCD-region order (and
+// with it what each L2 holds) is unchanged.  What the loop buys at a tile boundary:
+//   * the NEXT tile's first k-step (HA0(0), HB(0), HA1(0): 8 pieces per wave) is issued into k-step buffer 0 BEFORE the current tile's
+//     epilogue stores: vmcnt retires in issue order, so loads issued ahead of the stores land first and the stores drain behind them;
+//     the epilogue's LDS scratch (16 rows x 68 floats per wave, 34 KB) lives in buffer 1 meanwhile.  After the epilogue one barrier
+//     (every wave is done with the scratch), then HA0(1), HB(1) go to buffer 1 and the main loop starts on operands that landed long
+//     ago — the 7.7-11 k cycles a cold prologue waits for its first k-step (in-kernel stamps, profiles/r03_pp_stamps.txt) are gone for
+//     every tile but a workgroup's first;
+//   * no workgroup exit / dispatch / kernel-argument load between the tiles of a CU.
+// Only the wide epilogues (no other loads in flight but the residual's) prefetch across the epilogue; the generic epilogue (masks, second
+// residuals: the DPT convolutions, K >= 1152 there) keeps its 70 KB scratch at the start of LDS and re-runs the cold prologue per tile.
 template <bool ILVA, bool ILVW, bool EXT, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   static_assert(!(CONV && ILVA), "the convolution reads separate hi / lo activation arrays");
@@ -84,19 +107,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform (SGPR): LDS-DMA destinations, resource choice
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  int tm, tn;
-  region_tile(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.M, p.N, tiles_m * tiles_n > 256, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int tiles = tiles_m * tiles_n;
   const int wm0 = wr * WM, wn0 = wc * WN;
   const int nk = p.K >> 5;
 
   // ---------------------------------------------------------------- staging geometry (per operand: A and W may differ in layout)
   // piece = one wave-instruction of LDS-DMA = 1 KiB of the LDS image: 8 rows x 128 B (interleaved) or 16 rows x 64 B (separate arrays).
-  auto prow_of = [&](bool ilv) { return ilv ? (lane >> 3) : (lane >> 2); };  // row inside the piece
-  auto csrc_of = [&](bool ilv) {                                             // swizzled source chunk, bytes
+  // (lane_s: an opaque copy of the lane id, refreshed per tile — see the note at the epilogue call; the staging geometry is recomputed
+  // per tile from it instead of being held in registers across the main loop)
+  int lane_s = lane;
+  auto prow_of = [&](bool ilv) { return ilv ? (lane_s >> 3) : (lane_s >> 2); };  // row inside the piece
+  auto csrc_of = [&](bool ilv) {                                                 // swizzled source chunk, bytes
     const int pr = prow_of(ilv);
     const int csw = ilv ? (pr & 7) : ((0x1320 >> (((pr >> 2) & 3) * 4)) & 3);
-    return (((ilv ? (lane & 7) : (lane & 3)) ^ csw)) << 4;
+    return (((ilv ? (lane_s & 7) : (lane_s & 3)) ^ csw)) << 4;
   };
   constexpr int KSTEP_A = ILVA ? 128 : 64, KSTEP_W = ILVW ? 128 : 64;  // bytes of one k-step inside a source row
   // A pieces of this wave: list index i = 2 * wave + e (e = 0, 1) into the 16 pieces of a half (HA0; HA1 = the next 64 rows)
@@ -111,35 +135,57 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   auto piece_row0 = [&](bool ilv, int q) { return ilv ? q * 8 : (q & 15) * 16; };  // first tile row of piece q
   auto piece_lo = [&](bool ilv, int q) { return ilv ? 0 : (q >> 4); };             // 1: the piece belongs to the lo array (separate arrays)
 
-  const size_t a_base = CONV ? 0 : (size_t)m0 * p.lda, w_base = (size_t)n0 * p.ldw;
   const int cHs = CONV ? (p.cH >> p.cup) : 0, cWs = CONV ? (p.cW >> p.cup) : 0;
   // (conv) the resource covers exactly the activation: an offset past it — what a padding tap gets — reads as zeros
   const unsigned a_bytes = CONV ? (unsigned)min((size_t)0x7fffff00u, ((size_t)(p.M / (p.cHo * p.cWo)) * cHs * cWs * p.lda) * 2) : 0x7fffff00u;
-  const mvp_bf16* const pa_hi = p.a_hi + a_base;
-  const mvp_bf16* const pa_lo = (ILVA ? p.a_hi : p.a_lo) + a_base;
-  const mvp_bf16* const pw_hi = p.w_hi + w_base;
-  const mvp_bf16* const pw_lo = (ILVW ? p.w_hi : p.w_lo) + w_base;
+
+  // ---- state of the tile being STAGED (during an epilogue: already the next tile's)
+  int m0 = 0, n0 = 0;
+  const mvp_bf16 *pa_hi = p.a_hi, *pa_lo = p.a_hi, *pw_hi = p.w_hi, *pw_lo = p.w_hi;
   int a_voff[4], w_voff[4];  // per-lane byte offsets of this wave's pieces: [HA0 e0, HA0 e1, HA1 e0, HA1 e1], [HB 0..3]
-  int cv_img[4], cv_yx[4];  // (conv) per piece row: byte offset of its image, top-left input coordinates (y << 16 | x, biased by 0x4000)
+  int cv_img[4], cv_yx[4];   // (conv) per piece row: byte offset of its image, top-left input coordinates (y << 16 | x, biased by 0x4000)
+  int ct_ky[2], ct_kx[2], ct_c0[2];  // (conv) tap and channel of the NEXT k-step each half stages (k ascending per half)
+  typedef const __attribute__((address_space(4))) mvp_gemm_args kargs_t;  // the arguments, read in place from the kernel-argument segment
+  auto setup_tile = [&](int bid) {
+    lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    // (the arguments through an opaque pointer, so that the scalars of this block are re-read per tile instead of living — spilled to
+    // VGPR lanes — across the main loop)
+    kargs_t* kp = (kargs_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    kargs_t& p = *kp;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles = tiles_m * tiles_n;
+    int tm, tn;
+    region_tile(xcd_remap(bid, tiles), tiles_m, tiles_n, p.M, p.N, tiles > 256, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+    const size_t a_base = CONV ? 0 : (size_t)m0 * p.lda, w_base = (size_t)n0 * p.ldw;
+    pa_hi = p.a_hi + a_base;
+    pa_lo = (ILVA ? p.a_hi : p.a_lo) + a_base;
+    pw_hi = p.w_hi + w_base;
+    pw_lo = (ILVW ? p.w_hi : p.w_lo) + w_base;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int q = qa[e & 1] + (e >> 1) * HALF_STEP;
-    const int row = min(piece_row0(ILVA, q) + prow_of(ILVA), p.M - 1 - m0);  // rows past M re-read the last row (never stored)
-    a_voff[e] = row * p.lda * 2 + csrc_of(ILVA);
-    if (CONV) {
-      const int m = m0 + row;
-      const int x = m % p.cWo, t = m / p.cWo;
-      cv_img[e] = (t / p.cHo) * cHs * cWs * p.lda * 2 + csrc_of(false);
-      cv_yx[e] = (((t % p.cHo) * p.cstride - p.cpad + 0x4000) << 16) | (x * p.cstride - p.cpad + 0x4000);
+    for (int e = 0; e < 4; ++e) {
+      const int q = qa[e & 1] + (e >> 1) * HALF_STEP;
+      const int row = min(piece_row0(ILVA, q) + prow_of(ILVA), p.M - 1 - m0);  // rows past M re-read the last row (never stored)
+      a_voff[e] = row * p.lda * 2 + csrc_of(ILVA);
+      if (CONV) {
+        const int m = m0 + row;
+        const int x = m % p.cWo, t = m / p.cWo;
+        cv_img[e] = (t / p.cHo) * cHs * cWs * p.lda * 2 + csrc_of(false);
+        cv_yx[e] = (((t % p.cHo) * p.cstride - p.cpad + 0x4000) << 16) | (x * p.cstride - p.cpad + 0x4000);
+      }
     }
-  }
-  int ct_ky[2] = {0, 0}, ct_kx[2] = {0, 0}, ct_c0[2] = {0, 0};  // (conv) tap and channel of the NEXT k-step each half stages (k ascending per half)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int q = 4 * wave + e;
-    const int row = min(piece_row0(ILVW, q) + prow_of(ILVW), p.N - 1 - n0);
-    w_voff[e] = row * p.ldw * 2 + csrc_of(ILVW);
-  }
+    for (int e = 0; e < 2; ++e) ct_ky[e] = ct_kx[e] = ct_c0[e] = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = 4 * wave + e;
+      const int row = min(piece_row0(ILVW, q) + prow_of(ILVW), p.N - 1 - n0);
+      w_voff[e] = row * p.ldw * 2 + csrc_of(ILVW);
+    }
+  };
 
   auto stage_a = [&](int par, int kt, int half) {  // this wave's two pieces of HA<half> of k-step kt
 #if MVP_PP_ABLATE != 2
@@ -187,10 +233,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   const char* const w_rd = smem + PP_TILE_B + wn0 * WROWB;
 
   f32x4_t acc[NT][MT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   bf16x8_t a_hi[4], a_lo[4], w_hi[4], w_lo[4];
 
   auto read_a = [&](int par, int half) {
@@ -233,30 +275,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #endif
   };
 
-  // ---------------------------------------------------------------- prologue: HA0(0), HB(0), HA1(0), then what "P2(-1)" would issue
-  stage_a(0, 0, 0);
-  stage_w(0, 0);
-  stage_a(0, 0, 1);
-  if (nk > 1) {
-    stage_a(1, 1, 0);
-    stage_w(1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA0(0), HB(0) landed (this wave's pieces); HA1(0) x2, HA0(1) x2, HB(1) x4 in flight
-  } else {
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-#if MVP_PP_PRIO == 1
-  if (wr == 1) __builtin_amdgcn_s_setprio(1);
-#endif
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
-
 #if MVP_PP_STAMP
   uint64_t tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t s_e = __builtin_amdgcn_s_memtime(), s_x = 0;
-  const uint64_t t_l0 = s_e;
+  uint64_t s_e = 0, s_x = 0, t_pro = 0, t_loop = 0, t_epi = 0, t_mark = t_k0;
 #endif
-  auto kstep = [&](int t, auto PAR) {
+  bool relaxed = false;  // wave-uniform: the tile being computed had its first k-step prefetched across the previous tile's epilogue
+  auto kstep = [&](int t, auto PAR, auto FIRST) {
     constexpr int par = decltype(PAR)::value;
+    constexpr bool first = decltype(FIRST)::value != 0;  // the peeled k-step 0 (the relaxed wait below must not sit in the loop's code)
     // ---- P1, read interval: fragments of rows [0,64) + all W fragments; stage HA1(t+1)
 #if MVP_PP_ABLATE != 3
     read_w(par);
@@ -270,7 +296,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
         s_x = s_x0;
 #endif
       }
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA1(t) landed; HA0(t+1) x2, HB(t+1) x4, HA1(t+1) x2 stay in flight
+      if (MVP_PP_RELAXED && first && relaxed) {
+        // first phase of a tile whose first k-step was prefetched across the previous epilogue: HA1(0) is older than that epilogue's
+        // >= 32 stores, HA0(1) x2, HB(1) x4 and HA1(1) x2 — the stores get this phase and the next to drain (P2's vmcnt(8) needs them gone)
+        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA1(t) landed; HA0(t+1) x2, HB(t+1) x4, HA1(t+1) x2 stay in flight
+      }
     } else {
       {
         PP_STAMP(s_x0);
@@ -327,42 +359,151 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
     }
   };
 
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    kstep(t, ic<0>{});
-    kstep(t + 1, ic<1>{});
-  }
-  if (t < nk) kstep(t, ic<0>{});
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last interval
-#if MVP_PP_STAMP
-  const uint64_t t_l1 = __builtin_amdgcn_s_memtime();
-#endif
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  __syncthreads();  // every wave is done with the staging buffers -> the epilogue reuses them
-
 #ifndef MVP_PP_WIDE_EPILOGUE
 #define MVP_PP_WIDE_EPILOGUE 1  // 0 (diagnostic builds): always the generic epilogue
 #endif
   const int wide = (!EXT && MVP_PP_WIDE_EPILOGUE) ? gemm_epilogue_wide_variant(p) : 0;  // wave-uniform: kernel arguments only
-  switch (wide) {
-    case 1: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, false, true>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
-    case 2: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, false, true>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
-    case 3: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, true, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
-    case 4: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
-    case 5: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, true, false>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
-    case 6: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false, true>(p, acc, smem, wave, lane, m0, n0, wm0, wn0); break;
-    default: gemm_epilogue<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0);
+
+  // ---------------------------------------------------------------- first tile: the cold prologue — HA0(0), HB(0), HA1(0), then what "P2(-1)" would issue
+  int bid = blockIdx.x;
+  setup_tile(bid);
+  stage_a(0, 0, 0);
+  stage_w(0, 0);
+  stage_a(0, 0, 1);
+  stage_a(1, 1, 0);  // (nk >= 2: K >= 64, host check)
+  stage_w(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // HA0(0), HB(0) landed (this wave's pieces); HA1(0) x2, HA0(1) x2, HB(1) x4 in flight
+  __builtin_amdgcn_s_barrier();
+#if MVP_PP_PRIO == 1
+  if (wr == 1) __builtin_amdgcn_s_setprio(1);
+#endif
+
+  for (;;) {
+    const int m0c = m0, n0c = n0;  // the tile computed now (the staging state moves on to the next tile before the epilogue)
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: group 1 runs one barrier interval behind group 0
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#if MVP_PP_STAMP
+    s_e = __builtin_amdgcn_s_memtime();
+    t_pro += s_e - t_mark;
+    t_mark = s_e;
+#endif
+    kstep(0, ic<0>{}, ic<1>{});
+    int t = 1;
+    for (; t + 1 < nk; t += 2) {
+      kstep(t, ic<1>{}, ic<0>{});
+      kstep(t + 1, ic<0>{}, ic<0>{});
+    }
+    if (t < nk) kstep(t, ic<1>{}, ic<0>{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // group 0 waits out group 1's last interval
+#if MVP_PP_STAMP
+    {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      t_loop += now - t_mark;
+      t_mark = now;
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave is done with the staging buffers -> the epilogue and the next tile's first k-step reuse them
+
+    const int nbid = bid + (int)gridDim.x;
+    const bool has_next = nbid < tiles;
+    const bool pre = has_next && wide != 0 && MVP_PP_PREFETCH;
+    if (has_next) setup_tile(nbid);
+    // ahead of the epilogue's stores (vmcnt retires in order), behind its first loads: the next tile's first k-step into buffer 0
+    auto prefetch = [&]() {
+      if (pre) {
+        stage_a(0, 0, 0);
+        stage_w(0, 0);
+        stage_a(0, 0, 1);
+      }
+    };
+    char* const scratch = smem + (pre ? PP_BUF_B : 0);
+    // (an opaque per-tile copy of the lane id: the epilogue's per-lane constants would otherwise be hoisted out of the tile loop and
+    // held in registers across the main loop — 250+ VGPRs instead of ~220, and then no other wave fits on the SIMDs beside this kernel's two)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    // (and the kernel arguments read afresh from the kernel-argument segment through an opaque pointer, for the same reason: hoisted
+    // out of the tile loop the epilogue's ~60 scalars do not fit beside the main loop's and get spilled to VGPR lanes)
+#if MVP_PP_NOLOOP
+    const mvp_gemm_args& pe = p;
+#else
+    kargs_t* kp = (kargs_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    kargs_t& pe = *kp;
+#endif
+    switch (wide) {
+      case 1: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, false, true>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
+      case 2: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, false, true>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
+      case 3: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, true, true, false>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
+      case 4: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
+      case 5: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, true, false>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
+      case 6: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false, true>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
+      default:
+        gemm_epilogue<NT, MT, WN, EXT>(pe, acc, smem, wave, lane_e, m0c, n0c, wm0, wn0);
+        // The generic epilogue guards its rows with branches, and hipcc's wait-count pass must assume that a skipped row leaves that
+        // row's bias / residual / mask loads pending: without a wait it can SEE here it would protect their destination registers with
+        // an s_waitcnt vmcnt(0) inside the main loop — one drain of the LDS-DMA pipeline per k-step, for every epilogue variant.
+        if (has_next) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    }
+#if MVP_PP_STAMP
+    {
+      if (!has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last epilogue's stores have left
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      t_epi += now - t_mark;
+      t_mark = now;
+    }
+#endif
+    if (!has_next || MVP_PP_NOLOOP) break;
+    bid = nbid;
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's scratch reads are retired ...
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();        // ... and so are every other wave's: the LDS-DMA below may overwrite the scratch
+    if (!pre) {
+      stage_a(0, 0, 0);
+      stage_w(0, 0);
+      stage_a(0, 0, 1);
+    }
+    stage_a(1, 1, 0);
+    stage_w(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (pre) {
+      // HA0(0), HB(0) of this wave must have landed.  They are OLDER than everything the epilogue issued behind the prefetch hook —
+      // HA1(0) x2, at least 32 stores (gemm_epilogue_wide_ops::after_hook; more with residual / gate rows) — and than HA0(1) x2,
+      // HB(1) x4 just issued: 40 younger operations may stay in flight, the epilogue's stores among them, which drain under the
+      // first phases of the next tile instead of being waited for here.
+      static_assert(gemm_epilogue_wide_ops<false, false>::after_hook + 2 + 6 == 40 && gemm_epilogue_wide_ops<true, false>::after_hook >= 32 &&
+                    gemm_epilogue_wide_ops<false, true>::after_hook >= 32, "the relaxed waits count 32 stores per tile");
+      asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    } else {
+      // cold path: HA0(0), HB(0) landed; HA1(0) x2, HA0(1) x2, HB(1) x4 stay in flight
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    relaxed = pre;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
   }
 #if MVP_PP_STAMP
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the epilogue's stores have left
   const uint64_t t_e1 = __builtin_amdgcn_s_memtime();
   if (p.splitk_ws && wc == 0 && lane == 0) {
     uint64_t* dbg = (uint64_t*)p.splitk_ws + ((size_t)blockIdx.x * 2 + wr) * 16;
     for (int c = 0; c < 10; ++c) dbg[c] = tacc[c];
-    dbg[10] = t_l0 - t_k0; dbg[11] = t_l1 - t_l0; dbg[12] = t_e1 - t_l1; dbg[13] = t_k0; dbg[14] = t_e1;
+    dbg[10] = t_pro; dbg[11] = t_loop; dbg[12] = t_epi; dbg[13] = t_k0; dbg[14] = t_e1;
     dbg[15] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
+}
+
+// CUs of the device (the persistent grid): read once.
+inline int pp_cu_count() {
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    return cu;
+  }();
+  return n;
 }
 
 template <bool ILVA, bool ILVW, bool CONV = false>
@@ -374,12 +515,17 @@ int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  // persistent grid: one workgroup per CU (128 KB of LDS each), tiles dealt round by round; MVP_PP_PERSIST=0 (diagnostic): one tile
+  // per workgroup, the pre-round-4 launch.  (A multiple of 8 keeps a workgroup's tiles on one XCD slice of the region order.)
+  static const int persist = [] { const char* e = getenv("MVP_PP_PERSIST"); return (e ? atoi(e) : 1) && !MVP_PP_NOLOOP; }();
+  const int cus = pp_cu_count() & ~7;
+  const int grid = (persist && cus >= 8 && tiles > cus) ? cus : tiles;
   // (the gated-input-gradient combination has a wide epilogue of its own in the plain instantiation)
   const bool ext = (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) && gemm_epilogue_wide_variant(*a) != 6;
   if (ext)
-    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true, CONV>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true, CONV>), dim3(grid), dim3(512), PP_SMEM, s, *a);
   else
-    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, false, CONV>), dim3(tiles), dim3(512), PP_SMEM, s, *a);
+    hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, false, CONV>), dim3(grid), dim3(512), PP_SMEM, s, *a);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }
@@ -401,10 +547,15 @@ extern "C" int mvp_gemm_pp(const mvp_gemm_args* a, void* stream) {
   if ((a->lda & 7) || (a->ldw & 7) || a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   if (a->out_pair_layout != MVP_PAIR_SEPARATE && (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31))) return MVP_EINVAL;
+  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < 0 || (a->out_f16_col0 & 63) || !a->out_hi || (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE))) return MVP_EINVAL;
   // 32-bit per-lane byte offsets: 256 tile rows of the widest supported row must stay below 2 GiB
   if ((int64_t)256 * a->lda * 2 >= 0x7fffff00ll || (int64_t)256 * a->ldw * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+#ifdef MVP_PP_ONE  // diagnostic builds: only the interleaved-operand instantiation (fast compiles of experiments)
+  return (ilva && ilvw && !a->conv) ? launch_pp<true, true>(a, st) : MVP_EINVAL;
+#else
   if (a->conv) return ilvw ? launch_pp<false, true, true>(a, st) : launch_pp<false, false, true>(a, st);
   if (ilva) return ilvw ? launch_pp<true, true>(a, st) : launch_pp<true, false>(a, st);
   return ilvw ? launch_pp<false, true>(a, st) : launch_pp<false, false>(a, st);
+#endif
 }

@@ -38,6 +38,14 @@ __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint
   const bf16x2_t l = {(__bf16)(a - ha), (__bf16)(b - hb)};
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// The mixed form of mvp_gemm_args.out_f16_col0: hi = fp16(v) (rne), lo = bf16(v - hi), two values packed like split2_bf16.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f16x2_t h = {(_Float16)a, (_Float16)b};
+  hi = __builtin_bit_cast(uint32_t, h);
+  const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
+  lo = __builtin_bit_cast(uint32_t, l);
+}
 __device__ __forceinline__ uint32_t pack2(uint16_t a, uint16_t b) {
   return (uint32_t)a | ((uint32_t)b << 16);
 }

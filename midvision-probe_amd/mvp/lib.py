@@ -54,7 +54,8 @@ class GemmArgs(C.Structure):
                 ("conv", _i), ("cH", _i), ("cW", _i), ("cC", _i), ("cHo", _i), ("cWo", _i), ("ckh", _i), ("ckw", _i),
                 ("cstride", _i), ("cpad", _i), ("cup", _i), ("zero_page", _vp), ("relu_mask", _vp), ("out_mask", _vp), ("ldm", _i), ("mask_mode", _i),
                 ("residual2", _vp), ("act_after_res", _i), ("splitk", _i), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64),
-                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i), ("pair_layout", _i), ("out_pair_layout", _i)]
+                ("residual_hi", _vp), ("residual_lo", _vp), ("tile_policy", _i), ("pair_layout", _i), ("out_pair_layout", _i),
+                ("out_f16_col0", _i)]
 
 
 class LayerNormArgs(C.Structure):
@@ -64,7 +65,7 @@ class LayerNormArgs(C.Structure):
 
 class AttentionArgs(C.Structure):
     _fields_ = [("qkv_hi", _vp), ("qkv_lo", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("N", _i), ("H", _i),
-                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i), ("out_layout", _i)]
+                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i), ("out_layout", _i), ("v_format", _i)]
 
 
 class ClsRowsArgs(C.Structure):

@@ -186,8 +186,10 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
          act: int = lib.ACT_NONE, precision: int = PREC_BF16X3, lda=None, ldw=None, ldr=None, ldo=None, ldob=None,
          row_group=0, row_group_stride=0, row_group_off=0, res_row_mod=0, act_after_res=False, out_mask=None, ldm=0,
          splitk: Optional[int] = None, residual_pair: Optional[Pair] = None, streamk: Optional[bool] = None,
-         w_ilv: Optional[torch.Tensor] = None) -> None:
+         w_ilv: Optional[torch.Tensor] = None, f16_col0: int = 0) -> None:
     """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off.
+    f16_col0 > 0: columns from there on of the pair output are written as hi = fp16, lo = bf16 (mvp_gemm_args.out_f16_col0: the V
+    third of the fused qkv projection for ``attention(..., v_f16=True)``); no split-K / stream-K then.
     residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``.
     streamk: None = automatic (streamk_auto), True / False force the stream-K kernel on / off.
     w_ilv: the same weights as ``interleave_pair(w)``; handed to the large-M kernel when the dispatch rule picks it."""
@@ -207,6 +209,9 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     args.tile_policy = pipeline.tile_policy()
     args.pair_layout = lib.PAIR_A_ILV32 if a_ilv else lib.PAIR_SEPARATE  # (an interleaved A operand always goes to the large-M kernel)
     args.out_pair_layout = lib.PAIR_A_ILV32 if o_ilv else lib.PAIR_SEPARATE
+    if f16_col0:
+        args.out_f16_col0 = int(f16_col0)
+        splitk, streamk = 1, False
     if out_mask is not None:
         args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
     if residual_pair is not None:
@@ -252,13 +257,15 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pai
     _traced("hbm", "layernorm_kernel", 0, float(nb), lambda: lib.call("mvp_layernorm_fwd", a))
 
 
-def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None) -> None:
+def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None, v_f16: bool = False) -> None:
+    """``v_f16``: the V third of ``qkv`` holds hi = fp16, lo = bf16 (``gemm(..., f16_col0=2 * H * 64)``); the probabilities are then held
+    as one fp16 value (mvp_attention_args.v_format = MVP_ATT_V_F16; bf16x3 only)."""
     ilv = isinstance(out, IlvPair)
     if ilv:
         out, ld_out = (out.t, None), (ld_out if ld_out is not None else 2 * H * 64)
     a = lib.AttentionArgs(lib.ptr(qkv[0]), lib.ptr(qkv[1]), lib.ptr(out[0]), lib.ptr(out[1]), B, N, H,
                           ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision,
-                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE)
+                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE, 1 if v_f16 else 0)
     if _TRACE is None:
         lib.call("mvp_attention_fwd", a)
         return

@@ -170,6 +170,14 @@ def default_depth(probe=None, group: int = 1) -> int:
     return 2 if group > 1 else 4
 
 
+def rows_per_image(H: int, W: int, P: int) -> int:
+    """Token rows of one image, with the grid ViTEngine.tokens() builds: when either dimension is ragged against the patch size,
+    center_padding pads BOTH by ``P - dim % P`` — a full extra patch for the dimension that was not ragged (utils.py:55-72)."""
+    rh, rw = H % P, W % P
+    ph, pw = (0, 0) if (rh == 0 and rw == 0) else (P - rh, P - rw)
+    return 1 + ((H + ph) // P) * ((W + pw) // P)
+
+
 GROUP_ROWS = 19000  # token rows a grouped forward aims at: 6 batches of 16 x 197 = 18912 rows = 74 x {3, 9, 12} tiles of 256^2, 87 % of whole rounds of 256 CUs
 MAX_GROUP = 8
 
@@ -185,7 +193,7 @@ def default_group(model, images: torch.Tensor, depth: int) -> int:
         return max(1, min(MAX_GROUP, int(env)))
     P = int(getattr(model, "patch_size", 16))
     B, H, W = images.shape[0], images.shape[-2], images.shape[-1]
-    rows = B * (1 + (-(-H // P)) * (-(-W // P)))
+    rows = B * rows_per_image(H, W, P)
     return max(1, min(MAX_GROUP, int(round(GROUP_ROWS / rows))))
 
 
@@ -215,7 +223,7 @@ def default_span(model, images: torch.Tensor, depth: int, group: int) -> int:
             return 0
         P = int(getattr(model, "patch_size", 16))
         H, W = images.shape[-2], images.shape[-1]
-        rows = 1 + (-(-H // P)) * (-(-W // P))
+        rows = rows_per_image(H, W, P)
         unit = max(1, B // 8)
         T = min(((256 // (-(-C // 256))) * 256) // rows, MAX_GROUP * B) // unit * unit
     return T if (T > B and T % B) else 0
@@ -243,6 +251,12 @@ def _tensors(obj):
                 yield from _tensors(extra)
 
 
+def _multi_rank() -> bool:
+    import torch.distributed as dist
+
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
 class FeaturePipeline:
     """``submit(images)`` enqueues ``model(images)`` on a side stream; ``next()`` returns the oldest submitted features on the
     caller's current stream (event wait, no host sync) after applying the forward's deferred state updates.  ``depth`` = forwards
@@ -252,7 +266,7 @@ class FeaturePipeline:
     ``default_group`` at the first submit, what ``pipelined_features`` and bench.py ask for); ``free_slots()`` tells how many more
     forwards may be submitted.
 
-    ``graphs`` (default MVP_PIPELINE_GRAPHS != "0"): a ``graph_safe`` backbone's forward is captured once per (slot, input shape) in a
+    ``graphs`` (default: MVP_PIPELINE_GRAPHS when set, else on unless the job has more than one rank): a ``graph_safe`` backbone's forward is captured once per (slot, input shape) in a
     hipGraph and replayed — one launch call instead of ~100, 1.4 ms of host time per step down to 0.4, so a busy host (data loading,
     logging) no longer starves the device.  The first forward of every slot runs eagerly (it allocates the slot's buffers and builds
     lazily cached operands) and is then captured; later ones replay; the input batch is copied into the graph's static buffer.
@@ -299,11 +313,16 @@ class FeaturePipeline:
         self.run_ahead = int(os.environ.get("MVP_RUN_AHEAD", "8")) if run_ahead is None else int(run_ahead)
         self._issued = collections.deque()  # completion events of the newest ``run_ahead`` forwards
         if graphs is None:
-            # On by default, multi-rank jobs included: capture and replay beside RCCL's stream and watchdog thread were exercised on the
-            # one-GPU pool with a real RCCL all-reduce per step (tests/test_gpu_dist.py::test_rccl_world1_overlapped_allreduce_with_graph_replay:
-            # bit-identical trajectory); capture_error_mode="thread_local" keeps other threads' HIP calls out of the capture.
-            graphs = os.environ.get("MVP_PIPELINE_GRAPHS", "1") != "0"
+            # MVP_PIPELINE_GRAPHS wins when set.  Otherwise ON for single-process jobs and OFF (eager launches) for jobs with more than one
+            # rank: capture and replay beside RCCL's stream and watchdog thread have run on this pool only with ONE rank (a real RCCL
+            # all-reduce per step at world size 1: tests/test_gpu_dist.py::test_rccl_world1_*), never beside a collective that waits for
+            # peers — and a lazy capture (an epoch's ragged last batch, a rebind) is a device-wide sync that could land while the previous
+            # step's all-reduce is still pending.  With span forwards the replay saves ~100 launch calls per 110 images (~15 per probe
+            # step, against the ~115 the probe step itself makes), so the eager default costs multi-rank jobs little.
+            env = os.environ.get("MVP_PIPELINE_GRAPHS")
+            graphs = (env != "0") if env is not None else not _multi_rank()
         self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
+        self._warned_eager_span = False
         self._graphs = {}  # (slot, shape, dtype, training, engine id, group) -> dict(calls, graph, static_in, feats, deferred)
         self._stage = {}   # (slot, shape, dtype) -> stacked input buffer of eager grouped forwards
         self._static = {}  # (slot, shape, dtype) -> static input buffer of that slot's graphs
@@ -395,6 +414,11 @@ class FeaturePipeline:
             # pay a capture — a device-wide sync — inside the run
             ent = self._graphs.get(key) if self.graphs else None
             if ent is None:
+                if self.graphs and self._graphs and shape[0] == self.span and not self._warned_eager_span:
+                    self._warned_eager_span = True  # a FULL span without a graph: worth a word (short spans at a stream's end are expected)
+                    import warnings
+
+                    warnings.warn(f"mvp.pipeline: no captured graph for span pattern {G} on slot {slot}; this forward runs eagerly")
                 return self._eager(slot, self._stacked(slot, batches, shape), G)
             ent["calls"] += 1
         else:
@@ -403,8 +427,10 @@ class FeaturePipeline:
                 return self._eager(slot, self._stacked(slot, batches, shape) if G > 1 else first, G)
             ent = self._graphs.get(key)
             if ent is None:
-                mine = [k for k in self._graphs if k[0] == slot]
-                for k in mine[:-1] if len(mine) >= 2 else []:  # at most two shapes per slot (full batches + an epoch's ragged last one)
+                # at most two whole-batch shapes per slot (full batches + an epoch's ragged last one); the span patterns captured up
+                # front are not part of that budget (they are never re-captured: evicting them would silently turn those forwards eager)
+                mine = [k for k in self._graphs if k[0] == slot and not isinstance(k[5], Span)]
+                for k in mine[:-1] if len(mine) >= 2 else []:
                     del self._graphs[k]
                 ent = self._graphs[key] = dict(calls=0, graph=None)
             else:
@@ -423,8 +449,11 @@ class FeaturePipeline:
                 return self._capture(slot, s, batches, shape, G, ent, eng)  # (its replay computed this forward's features)
         self._fill(ent["static_in"], batches, G)
         ent["graph"].replay()
+        from .vit import register_pack
+
         for pk in ent["packs"]:
-            pk.generation += 1  # the host code that counts rewrites of the packing does not run on a replay
+            pk.generation += 1  # the host code that counts rewrites of the packing does not run on a replay ...
+            register_pack(pk.source_refs, pk)  # ... nor does the registration: an entry aged out of the registry (other pipelines' packings) comes back
         return ent["feats"], ent["deferred"]
 
     def _precapture_spans(self, s, sample: torch.Tensor) -> None:

@@ -70,7 +70,10 @@ def _padded(B, h, w, Ctot):
 PackedFeatures.padded = staticmethod(_padded)
 
 _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
-_PACK_REGISTRY_MAX = 64  # one entry per (pipeline slot, batch of a grouped forward)
+# one entry per (pipeline slot, forward shape, batch of the forward): a span pipeline keeps 2 slots x two shapes (floor / ceil of T / B
+# whole batches) x up to 14 batches = 54 entries at B = 8, and a model has a train and an eval pipeline; a graph replay re-registers
+# its packings (pipeline._forward), so an entry that ages out anyway comes back at its forward's next replay
+_PACK_REGISTRY_MAX = 256
 
 
 def _ver(t: torch.Tensor) -> int:
@@ -115,6 +118,7 @@ class ViTEngine:
         self.device = torch.device(device)
         self.precision = parse_precision(precision)
         self.heads, self.patch, self.ln_eps = heads, patch, ln_eps
+        self.att_v_f16 = self.precision == lib.PREC_BF16X3 and os.environ.get("MVP_ATT_V", "f16") != "pair"
         self.pos_embed_mode = pos_embed_mode
         sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.C = sd["cls_token"].shape[-1]
@@ -262,8 +266,12 @@ class ViTEngine:
         blk, C, M, pr = self.blocks[i], self.C, B * N, self.precision
         x = ws["x"]
         ops.layernorm(x, blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps)
-        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=pr, w_ilv=blk.get("qkv_w_ilv"))
-        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr)
+        # bf16x3: the V third of qkv leaves the GEMM as hi = fp16, lo = bf16, and the attention kernel holds its probabilities as one
+        # fp16 value (csrc/attention.hip, VF16; MVP_ATT_V=pair brings back the bf16-pair probabilities of rounds 1-3)
+        vf16 = self.att_v_f16
+        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=pr, w_ilv=blk.get("qkv_w_ilv"),
+                 f16_col0=2 * C if vf16 else 0)
+        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16)
         ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=pr, w_ilv=blk.get("proj_w_ilv"))
         ops.layernorm(x, blk["n2w"], blk["n2b"], ws["xn"], M, C, self.ln_eps)
         ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=pr, w_ilv=blk.get("fc1_w_ilv"))

@@ -14,6 +14,7 @@ for p in (REPO, os.path.join(REPO, "midvision-probe_amd")):
         sys.path.insert(0, p)
 
 D, DEPTH, HEADS, B, H, W, STEPS = 128, 4, 2, 3, 64, 96, 3
+PIPE_STEPS = 7  # mode "pipe": 21 images per rank = three span forwards of 7
 
 
 def build(dev, probe_seed, overlap):
@@ -51,9 +52,20 @@ def main():
     model, probe, opt, sched = build(dev, probe_seed=100 + rank, overlap=overlap)
     loss_fn = DepthLoss()
     losses = []
-    for s in range(STEPS):
-        images, tgt = batch(rank, s, dev)
-        losses.append(train_depth_step(model, probe, opt, sched, loss_fn, images, tgt).item())
+    if len(sys.argv) > 3 and sys.argv[3] == "pipe":
+        # the per-rank pipeline of a multi-GPU job with graphs switched on: span forwards (7 images over batches of 3) on a side stream,
+        # (slot, carry) graphs captured up front and replayed, the all-reduce of step t pending while the forwards of later batches run
+        from mvp.pipeline import FeaturePipeline, pipelined_features
+
+        pipe = FeaturePipeline(model, 2, graphs=True, group=None, span=7)
+        bs = [batch(rank, s, dev) for s in range(PIPE_STEPS)]
+        for (img, tgt), f in pipelined_features(model, bs, pipe=pipe):
+            losses.append(train_depth_step(model, probe, opt, sched, loss_fn, None, tgt, feats=f).item())
+        assert pipe.span == 7 and pipe.graphs and sum(e["calls"] for e in pipe._graphs.values()) >= 2
+    else:
+        for s in range(STEPS):
+            images, tgt = batch(rank, s, dev)
+            losses.append(train_depth_step(model, probe, opt, sched, loss_fn, images, tgt).item())
     opt.finish_pending()
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=opt.flat_param.cpu().numpy(), losses=np.array(losses),

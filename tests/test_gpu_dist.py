@@ -25,13 +25,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(out_dir, overlap, world=2):
+def _run_ranks(out_dir, overlap, world=2, mode=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    MVP_DIST_BACKEND="gloo", MVP_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_rank.py"), str(out_dir), str(int(overlap))], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_rank.py"), str(out_dir), str(int(overlap))] + ([mode] if mode else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -47,7 +47,7 @@ def _run_ranks(out_dir, overlap, world=2):
     return [np.load(os.path.join(out_dir, f"rank{r}.npz")) for r in range(world)]
 
 
-def _emulate(world=2):
+def _emulate(world=2, steps=None):
     import _dist_rank as R
     from evals.utils.losses import DepthLoss
     from mvp import functional as MF
@@ -56,7 +56,7 @@ def _emulate(world=2):
     model, probe, opt, sched = R.build(dev, probe_seed=100, overlap=False)  # rank 0's seed: what the broadcast distributes
     loss_fn = DepthLoss()
     losses = [[] for _ in range(world)]
-    for s in range(R.STEPS):
+    for s in range(R.STEPS if steps is None else steps):
         grads = []
         for r in range(world):
             images, tgt = R.batch(r, s, dev)
@@ -93,7 +93,60 @@ def test_two_rank_product_step_matches_mean_gradient_emulation(tmp_path):
         assert not np.array_equal(r0["losses"], r1["losses"])  # the ranks really saw different shards
 
 
-def test_rccl_world1_overlapped_allreduce_with_graph_replay(tmp_path):
+@pytest.mark.timeout(900)
+def test_two_rank_span_pipelines_with_graph_replay_match_mean_gradient_emulation(tmp_path):
+    """The branch an 8-GPU job takes when hipGraph replay is switched on (MVP_PIPELINE_GRAPHS=1; multi-rank jobs default to eager
+    launches): every rank keeps its OWN span pipeline — forwards of 7 images over batches of 3 on a side stream, the (slot, carry)
+    graphs captured at the first submit and replayed, a batch carried across forwards — while step t's flat-gradient all-reduce
+    (async, overlapped) is still pending.  Two ranks share cuda:0 over gloo (slow: their queues are time-sliced; a correctness run).
+    Replicas stay bit-identical and equal the single-process mean-gradient emulation on the serial loop, bit for bit.
+    (Reference: train_depth.py:620-622, DDP wrap of the probe; 99-144, the loop.)"""
+    import _dist_rank as R
+
+    assert torch.cuda.is_available()
+    ref_flat, ref_losses = _emulate(steps=R.PIPE_STEPS)
+    r0, r1 = _run_ranks(tmp_path, True, mode="pipe")
+    assert int(r0["world"]) == 2 and str(r0["backend"]) == "gloo"
+    np.testing.assert_array_equal(r0["flat"], r1["flat"])
+    np.testing.assert_array_equal(r0["flat"], ref_flat)
+    np.testing.assert_array_equal(r0["losses"], ref_losses[0])
+    np.testing.assert_array_equal(r1["losses"], ref_losses[1])
+
+
+def test_spair_pair_sharding_two_ranks_equals_single_process(tmp_path):
+    """BASELINE config #5 shards image PAIRS over the ranks (evaluate_spair_correspondence.py:104-121 is the single loop):
+    two ranks (gloo, one shared card) each evaluate pairs r, r + 2, ... through their own forward pipeline, gather the per-pair error /
+    index vectors with one all_gather_object and re-sort them into dataset order — every rank must return exactly what one process
+    returns for the whole dataset (recall and confusion matrix, bit for bit; 7 pairs: uneven shards)."""
+    import _spair_rank as S
+    from mvp import spair
+
+    assert torch.cuda.is_available()
+    recall, conf = spair.evaluate_dataset(S.build(torch.device("cuda:0")), S.dataset(), 0.10)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MVP_DIST_BACKEND="gloo", MVP_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_spair_rank.py"), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, o.decode(errors="replace")[-3000:]
+    for r in range(2):
+        got = np.load(os.path.join(tmp_path, f"spair{r}.npz"))
+        assert int(got["world"]) == 2 and str(got["backend"]) == "gloo"
+        assert float(got["recall"]) == recall
+        np.testing.assert_array_equal(got["conf"], conf.numpy())
+    assert conf.sum().item() > 0 and 0.0 <= recall <= 100.0
+
+
+@pytest.mark.parametrize("mode", ["groups", "spans"])
+def test_rccl_world1_overlapped_allreduce_with_graph_replay(tmp_path, mode):
     """The RCCL branch of FlatAdamW on the one GPU this pool has: init_process_group("nccl", world_size=1) and the
     ``force_comm`` hook send every step's flat gradient through a real RCCL all_reduce(async_op=True) -> work.wait() -> AdamW, with the
     pipeline's grouped forwards replaying captured hipGraphs beside RCCL's stream and watchdog thread.  The trajectory (losses, weights,
@@ -101,7 +154,10 @@ def test_rccl_world1_overlapped_allreduce_with_graph_replay(tmp_path):
     out = tmp_path / "w1.npz"
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-    p = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_world1.py"), str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    # mode "spans": the pipeline shape multi-GPU jobs run when graphs are switched on — span forwards (7 images over batches of 3), the
+    # pre-captured (slot, carry) graphs, a batch carried across forwards, and a ragged last batch whose eager forwards run beside the
+    # all-reduce still pending from the previous step
+    p = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_world1.py"), str(out), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
     assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
     r = np.load(out)
     assert str(r["backend"]) == "nccl"

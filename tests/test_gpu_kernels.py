@@ -229,37 +229,59 @@ def test_layernorm(dev, C):
     assert rel_l2(out[0].float().cpu().numpy(), ref.numpy()) < 4e-3  # hi alone is bf16-accurate
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16"])
+def _v_third_as_f16_bf16(qp, C):
+    """The V third of a split qkv pair re-written as hi = fp16(v), lo = bf16(v - hi) — what the qkv GEMM's epilogue writes under
+    mvp_gemm_args.out_f16_col0 (same arrays: the fp16 bits sit in the bf16-typed hi array)."""
+    hi, lo = qp[0].clone(), qp[1].clone()
+    v = (qp[0][:, 2 * C:].float() + qp[1][:, 2 * C:].float())
+    vh = v.half()
+    hi[:, 2 * C:] = vh.view(torch.bfloat16)
+    lo[:, 2 * C:] = (v - vh.float()).bfloat16()
+    return hi, lo
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_vf16", "bf16"])
 @pytest.mark.parametrize("BNH", [(2, 197, 12), (1, 1201, 3), (3, 25, 2), (2, 64, 1), (1, 129, 2)])
 def test_attention(dev, precision, BNH):
+    """softmax(Q K^T / 8) V against fp64 (ibot_transformers.py:129-145).  bf16x3_vf16 = the form the ViT engine runs since round 4:
+    V as hi fp16 + lo bf16, the probabilities held as ONE fp16 value (2^-12 relative each, averaged over the keys) — the measured error
+    is printed; the bound is 3e-4 (the bf16-pair probabilities of rounds 1-3: 6e-5)."""
     from mvp import lib, ops
     from mvp.vit import parse_precision
 
     B, N, H = BNH
-    pr = parse_precision(precision)
+    vf16 = precision.endswith("_vf16")
+    pr = parse_precision(precision.replace("_vf16", ""))
     C = H * 64
     g = torch.Generator().manual_seed(N)
     qkv = torch.randn(B * N, 3 * C, generator=g)
     qkv[:, :C] *= 2.0  # sharpen the softmax a little
     qd = qkv.to(dev)
     qp = ops.split_bf16(qd, pr)
+    if vf16:
+        qp = _v_third_as_f16_bf16(qp, C)
     src = (_bf16_round(qkv) if pr == lib.PREC_BF16 else qkv).double()
     t = src.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     att = ((t[0] @ t[1].transpose(-2, -1)) * 0.125).softmax(-1)
     ref = (att @ t[2]).transpose(1, 2).reshape(B * N, C)
     out = ops.empty_pair((B * N, C), lib.PREC_BF16X3, dev)
     out[0].fill_(float("nan")); out[1].fill_(float("nan"))
-    ops.attention(qp, out, B, N, H, 0.125, pr)
+    ops.attention(qp, out, B, N, H, 0.125, pr, v_f16=vf16)
     torch.cuda.synchronize()
     got = (out[0].float() + out[1].float()).cpu()
     assert torch.isfinite(got).all()
     # bf16 mode: P is rounded to bf16 inside the kernel (the reference is not) -> ~2^-9 error
-    tol = 6e-5 if pr == lib.PREC_BF16X3 else 4e-3
-    assert rel_l2(got.numpy(), ref.numpy()) < tol, (BNH, precision)
+    tol = (3e-4 if vf16 else 6e-5) if pr == lib.PREC_BF16X3 else 4e-3
+    err = rel_l2(got.numpy(), ref.numpy())
+    print(f"attention {precision} B,N,H={BNH}: rel-L2 vs fp64 {err:.2e} (bound {tol:.0e})")
+    assert err < tol, (BNH, precision, err)
 
 
-def test_attention_online_softmax_rescale(dev):
-    """Force the running-max rescale branch: one late key dominates one query row."""
+@pytest.mark.parametrize("vf16", [False, True])
+def test_attention_online_softmax_rescale(dev, vf16):
+    """Force the running-max rescale branch: one late key dominates one query row.  (vf16: the running maximum moves only when a row's
+    maximum rises by more than 2^6 — here by 128 log2(e) in the fifth tile, for ONE row of the wave; a second spike of +3 exp2 units
+    in the third tile stays below the threshold and must be absorbed by probabilities above 1.)"""
     from mvp import lib, ops
 
     B, N, H = 1, 300, 1
@@ -267,15 +289,20 @@ def test_attention_online_softmax_rescale(dev):
     qkv = torch.randn(B * N, 192, generator=g)
     qkv[5, :64] = 4.0
     qkv[290, 64:128] = 4.0  # key 290 (5th key tile) matches query 5 strongly: score 4*4*64*0.125 = 128
+    qkv[9, :64] = 1.0
+    qkv[150, 64:128] = 0.9  # key 150 (3rd tile) for query 9: score 0.9*64*0.125 = 7.2 = 10.4 exp2 units... above the other keys' ~+-3
     qp = ops.split_bf16(qkv.to(dev))
+    if vf16:
+        qp = _v_third_as_f16_bf16(qp, 64)
     t = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     ref = (((t[0] @ t[1].transpose(-2, -1)) * 0.125).softmax(-1) @ t[2]).transpose(1, 2).reshape(N, 64)
     out = ops.empty_pair((N, 64), lib.PREC_BF16X3, dev)
-    ops.attention(qp, out, B, N, H, 0.125, lib.PREC_BF16X3)
+    ops.attention(qp, out, B, N, H, 0.125, lib.PREC_BF16X3, v_f16=vf16)
     torch.cuda.synchronize()
     got = (out[0].float() + out[1].float()).cpu()
-    assert rel_l2(got.numpy(), ref.numpy()) < 6e-5
-    assert rel_l2(got[5].numpy(), ref[5].numpy()) < 6e-5
+    tol = 3e-4 if vf16 else 6e-5
+    assert rel_l2(got.numpy(), ref.numpy()) < tol
+    assert rel_l2(got[5].numpy(), ref[5].numpy()) < tol and rel_l2(got[9].numpy(), ref[9].numpy()) < tol
 
 
 @pytest.mark.parametrize("BNC", [(2, 197, 768), (3, 25, 128), (1, 1201, 768)])
@@ -445,6 +472,49 @@ def test_gemm_tile_policies_at_the_timed_shapes_vs_fp64(dev, policy, shape):
             assert (d.norm() / r.norm()).item() < 7e-5
             outs[pol] = (out, op)
         assert torch.equal(outs[policy][0], outs["alone"][0]) and torch.equal(outs[policy][1][0], outs["alone"][1][0]) and torch.equal(outs[policy][1][1], outs["alone"][1][1])
+
+
+@pytest.mark.parametrize("shape", [(21670, 2304, 768), (43900, 768, 160), (17000, 1800, 96), (9000, 516, 224), (70000, 264, 64)])
+def test_gemm_pp_tile_loop_and_wide_epilogues_equal_the_tile_kernels(dev, shape):
+    """Round 4: the large-M kernel is persistent over tiles (grid = CUs; the next tile's first k-step is fetched ahead of the current
+    tile's epilogue stores) and its wide epilogues are branch-free buffer stores.  With more tiles than CUs (765 / 516 / 536 / 1096),
+    a ragged last row tile, N ragged against 256 (1800), N % 8 != 0 (516: the generic epilogue inside the tile loop) and odd k-step
+    counts (K = 160, 96, 224: 5, 3, 7 steps), in the output forms the ViT blocks use — pair only (qkv, fc1 + GELU), fp32 + residual
+    (proj, fc2), fp32 only — the results are the tile kernels' bit for bit (which the other tests hold to fp64), and a second launch
+    reproduces the first."""
+    import ctypes as C
+
+    from mvp import lib, ops
+
+    M, N, K = shape
+    ap, wp, bias, res, ref = _gemm_case(dev, M, N, K, 11 + M + N)
+    so = lib.load()
+    forms = (("pair", lib.ACT_NONE, False), ("pair", lib.ACT_GELU, False), ("f32", lib.ACT_NONE, True), ("f32", lib.ACT_GELU, False), ("f32", lib.ACT_NONE, False))
+    for form, act, use_res in forms:
+        r = ref
+        if act == lib.ACT_GELU:
+            r = F.gelu(r)
+        if use_res:
+            r = r + res.double()
+        outs = {}
+        for pol in ("tile", "pp", "pp_again"):
+            out = torch.full((M, N), float("nan"), device=dev) if form == "f32" else None
+            op = ops.empty_pair((M, N), lib.PREC_BF16X3, dev) if form == "pair" else None
+            if op is not None:
+                op[0].fill_(float("nan")); op[1].fill_(float("nan"))
+            a = lib.GemmArgs(lib.ptr(ap[0]), lib.ptr(ap[1]), lib.ptr(wp[0]), lib.ptr(wp[1]), lib.ptr(bias), lib.ptr(res) if use_res else None,
+                             lib.ptr(out), lib.ptr(op[0]) if op else None, lib.ptr(op[1]) if op else None, M, N, K, K, K, N, N, N, act, lib.PREC_BF16X3, 0, 0, 0, 0)
+            a.tile_policy = lib.TILES_NO_PP if pol == "tile" else 0
+            lib.check((so.mvp_gemm_bias_act_res if pol == "tile" else so.mvp_gemm_pp)(C.byref(a), lib.stream_ptr()), pol)
+            torch.cuda.synchronize()
+            val = out.double() if out is not None else op[0].double() + op[1].double()
+            assert ((val - r).norm() / r.norm()).item() < 7e-5, (shape, pol, form, act, use_res)
+            outs[pol] = (out, op)
+        for pol in ("pp", "pp_again"):
+            if form == "f32":
+                assert torch.equal(outs[pol][0], outs["tile"][0]), (shape, pol, form, act, use_res)
+            else:
+                assert torch.equal(outs[pol][1][0], outs["tile"][1][0]) and torch.equal(outs[pol][1][1], outs["tile"][1][1]), (shape, pol, form, act)
 
 
 @pytest.mark.parametrize("shape", [(18912, 3072, 768), (5000, 768, 3072), (300, 512, 96)])

@@ -79,7 +79,11 @@ def main():
     # ------------------------------------------------------------------ correctness
     cases = [(256, 256, 64, {}), (300, 520, 96, dict(act=1)), (3152, 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
              (3152, 2304, 768, {}), (1000, 3072, 768, dict(act=1)), (777, 768, 3072, dict(residual=True, f32_out=True)),
-             (12608, 768, 768, dict(residual=True, pair_out=False, f32_out=True))]
+             (12608, 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
+             # more tiles than CUs: the persistent tile loop (765 / 1020 tiles of pair output, 516 with the residual epilogue, ragged last
+             # row tile and a ragged last column tile)
+             (21670, 2304, 768, {}), (21670, 3072, 768, dict(act=1)), (43900, 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
+             (17000, 1800, 96, dict(residual=True, f32_out=True))]
     for m, n, k, kw in cases:
         d = mk(m, n, k, **kw)
         A = (d["a"][0].double() + d["a"][1].double())
@@ -117,17 +121,18 @@ def main():
         print(f"check M={m} N={n} K={k} {kw}: rel-max-err tile {outs['tile'][2]:.2e} pp_sep {outs['pp_sep'][2]:.2e} pp_ilv {outs['pp_ilv'][2]:.2e}; "
               f"bit-identical to tile: {same}  {'OK' if good else 'FAIL'}", flush=True)
     # reproducibility / race screen: the same launch many times must give the same bits
-    d = mk(3152, 768, 3072, residual=True, pair_out=False, f32_out=True)
-    for which in ("pp_sep", "pp_ilv"):
-        base = torch.empty(3152, 768, device=dev)
-        run(d, which, None, base)
-        bad = 0
-        for _ in range(200):
-            o = torch.empty(3152, 768, device=dev)
-            run(d, which, None, o)
-            bad += int(not torch.equal(o, base))
-        ok = ok and bad == 0
-        print(f"repro {which}: {bad} of 200 launches differ", flush=True)
+    for (rm, rn, rk) in ((3152, 768, 3072), (21670, 768 * 2, 768)):  # one tile per workgroup / two to three tiles per workgroup
+        d = mk(rm, rn, rk, residual=True, pair_out=False, f32_out=True)
+        for which in ("pp_sep", "pp_ilv"):
+            base = torch.empty(rm, rn, device=dev)
+            run(d, which, None, base)
+            bad = 0
+            for _ in range(200):
+                o = torch.empty(rm, rn, device=dev)
+                run(d, which, None, o)
+                bad += int(not torch.equal(o, base))
+            ok = ok and bad == 0
+            print(f"repro {which} M={rm} N={rn} K={rk}: {bad} of 200 launches differ", flush=True)
     print("CHECK", "PASS" if ok else "FAIL", flush=True)
     if "--build-only" in sys.argv:
         return 0
@@ -137,36 +142,40 @@ def main():
     if "--stamp" in sys.argv:  # in-kernel s_memtime breakdown of the phases (diagnostic build, MVP_PP_STAMP)
         lst = build_ablate(1, "MVP_PP_STAMP", "stamp")
         names = ["issue (reads + DMA)", "counted waits", "barrier 1", "MFMA cluster", "barrier 2"]
-        for B in (64, 96):
+        for B in (96, 110):
             M = B * 197
-            for name, n, k, kw in (("qkv", 2304, 768, {}), ("fc2", 768, 3072, dict(residual=True, pair_out=False, f32_out=True))):
-                for ilv in (1, 0):
+            for name, n, k, kw in (("qkv", 2304, 768, {}), ("fc1", 3072, 768, dict(act=1)), ("fc2", 768, 3072, dict(residual=True, pair_out=False, f32_out=True))):
+                for ilv in (1,):
                     d = mk(M, n, k, **kw)
                     out = ops.empty_pair((M, n), 3, dev) if d["pair_out"] else None
                     o32 = torch.empty(M, n, device=dev) if d["f32_out"] else None
                     tiles = ((M + 255) // 256) * ((n + 255) // 256)
-                    dbg = torch.zeros(tiles * 2 * 16, dtype=torch.int64, device=dev)
+                    grid = min(tiles, 256)  # the persistent launch: one workgroup per CU
+                    per_wg = torch.tensor([len(range(w, tiles, grid)) for w in range(grid)], dtype=torch.float64, device=dev)
+                    dbg = torch.zeros(grid * 2 * 16, dtype=torch.int64, device=dev)
                     g = args_for(d, 3 if ilv else 0, out, o32)
                     g.splitk_ws, g.splitk_ws_bytes = dbg.data_ptr(), dbg.numel() * 8
                     for _ in range(3):
                         rc = lst.mvp_gemm_pp(C.byref(g), st)
                     torch.cuda.synchronize()
                     assert rc == 0
-                    raw = dbg.view(tiles, 2, 16).double()
-                    t = raw[:, :, :10].reshape(tiles, 2, 2, 5) / (k // 32)  # cycles per phase, [tile, group, phase type, segment]
+                    raw = dbg.view(grid, 2, 16).double()
+                    t = raw[:, :, :10].reshape(grid, 2, 2, 5) / (k // 32) / per_wg.view(grid, 1, 1, 1)  # cycles per phase, [workgroup, group, phase type, segment]
                     mean = t.mean(dim=0)
-                    print(f"stamp B={B} {name} ilv={ilv} tiles={tiles}: cycles per phase (mean over workgroups; group 0 | group 1)")
+                    print(f"stamp B={B} {name} ilv={ilv} tiles={tiles} workgroups={grid}: cycles per phase (mean over workgroups; group 0 | group 1)")
                     for ph in range(2):
                         print(f"   P{ph + 1}: " + "  ".join(f"{names[c]}={mean[0, ph, c]:.0f}|{mean[1, ph, c]:.0f}" for c in range(5))
                               + f"   total={mean[0, ph].sum():.0f}|{mean[1, ph].sum():.0f}", flush=True)
-                    pro, loop, epi = raw[:, :, 10].mean().item(), raw[:, :, 11].mean().item(), raw[:, :, 12].mean().item()
-                    span = (raw[:, :, 14].max() - raw[:, :, 13].min()).item()  # first workgroup start -> last workgroup end (s_memtime is one clock per XCD: indicative)
-                    print(f"   per workgroup: prologue {pro:.0f} cycles, main loop {loop:.0f}, epilogue + store drain {epi:.0f}; kernel span ~{span:.0f} cycles", flush=True)
+                    # per TILE: what precedes the main loop (cold prologue of the first tile, tile switch of the others), the main loop, the epilogue
+                    pro, loop, epi = ((raw[:, :, c] / per_wg.view(grid, 1)).mean().item() for c in (10, 11, 12))
+                    life = (raw[:, :, 14] - raw[:, :, 13]).mean().item()
+                    print(f"   per tile: prologue / tile switch {pro:.0f} cycles, main loop {loop:.0f}, epilogue {epi:.0f}; workgroup lifetime {life:.0f} cycles "
+                          f"for {per_wg.mean().item():.2f} tiles", flush=True)
         return 0
 
     # ------------------------------------------------------------------ timing
-    Bs = [int(x) for x in (sys.argv[sys.argv.index("--B") + 1].split(",") if "--B" in sys.argv else ["16", "64", "96"])]
-    variants = ["tile", "pp_sep", "pp_wilv", "pp_ailv", "pp_ilv"]
+    Bs = [int(x) for x in (sys.argv[sys.argv.index("--B") + 1].split(",") if "--B" in sys.argv else ["16", "64", "96", "110"])]
+    variants = ["tile", "pp_sep", "pp_wilv", "pp_ailv", "pp_ilv"] if "--ilv-only" not in sys.argv else ["pp_ilv"]
     extra = {}
     if "--ablate" in sys.argv:
         for n, nm in ((1, "no_mfma"), (2, "no_dma"), (3, "no_read")):
@@ -174,6 +183,16 @@ def main():
     if "--prio" in sys.argv:  # priority forms of the main loop (MVP_PP_PRIO): static priority for waves 4-7 / no priority instructions
         extra["static_prio"] = build_ablate(1, "MVP_PP_PRIO", "prio")
         extra["no_prio"] = build_ablate(2, "MVP_PP_PRIO", "prio")
+    if "--persist-ab" in sys.argv:  # the tile loop of round 4: one tile per workgroup (no loop) / the loop without the prefetch ahead of the epilogue
+        extra["one_tile_per_wg"] = build_ablate(1, "MVP_PP_NOLOOP", "noloop")
+        extra["loop_cold_prologue"] = build_ablate(0, "MVP_PP_PREFETCH", "prefetch")
+        extra["loop_strict_first_wait"] = build_ablate(0, "MVP_PP_RELAXED", "relaxed")
+        r03 = os.path.join(REPO, "tools", "micro", "libpp_r03.so")  # round 3's kernel (git show 6fdc23d:.../gemm_pp.hip + gemm_epilogue.h), built in the build container
+        if os.path.exists(r03):
+            l3 = C.CDLL(r03)
+            l3.mvp_gemm_pp.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
+            l3.mvp_gemm_pp.restype = C.c_int
+            extra["round3_kernel"] = l3
     if "--epilogue-ab" in sys.argv:  # the generic epilogue (gemm_epilogue) instead of the wide one, same main loop
         extra["generic_epilogue"] = build_ablate(0, "MVP_PP_WIDE_EPILOGUE", "wide")
     for B in Bs:
