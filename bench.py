@@ -219,6 +219,19 @@ def self_launch(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _gemm_tiles_label(pipe, tiles_shared, B, H, W):
+    """Which kernel family the backbone GEMMs of a forward run on (the mirror of pp_takes() in csrc/gemm.hip, mvp.ops.gemm_tile)."""
+    from mvp import ops
+    from mvp.pipeline import rows_per_image
+
+    imgs = pipe.span or B * max(1, pipe.group or 1)
+    M = imgs * rows_per_image(H, W, 16)
+    fam = {ops.gemm_tile(M, n, k, tile_policy=1 if tiles_shared else 0) for n, k in ((2304, 768), (768, 768), (3072, 768), (768, 3072))}
+    if all(t.startswith("pp ") for t in fam):
+        return f"large-M 256x256 ping-pong kernel (gemm_pp.hip), M = {M} rows per forward"
+    return ("shared-chip " if tiles_shared else "alone ") + " / ".join(sorted(fam)) + f" at M = {M}"
+
+
 def main():
     args = parse_args()
     warnings.simplefilter("ignore")
@@ -381,7 +394,7 @@ def main():
     images_per_s = world * B * args.steps / dt
 
     # ---------------- serial leg (reported next to `value`): the same steps as ONE kernel chain on one stream (inflight = 1)
-    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "span_images": (pipe.span or None), "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": ("large-M 256x256 ping-pong kernel (gemm_pp.hip)" if pipe.group > 1 else "shared-chip (128x128)" if tiles_shared else "alone"),
+    pipeline_info = {"inflight": pipe.depth, "group": pipe.group, "span_images": (pipe.span or None), "streams": pipe.chains, "hipgraph_forward": pipe.graphs, "gemm_tiles": _gemm_tiles_label(pipe, tiles_shared, B, H, W),
                      "what": "frozen forwards of upcoming batches (stacked `group` at a time into one chain of launches: same bits per batch) run on side "
                              "HIP streams under the probe steps of the current batches; every step still runs its own full forward + probe "
                              "forward/backward/AdamW inside the timed region, and the pipeline is empty at both of its barriers"}
@@ -404,9 +417,11 @@ def main():
     sustained = None
     if args.sustained_steps > 0:
         barrier()
+        w0 = pipe.throttle_wait_s
         t1 = time.perf_counter()
         run_steps(args.warmup + args.steps, args.sustained_steps)
-        host_dt = time.perf_counter() - t1  # host enqueue time of the leg (the device runs behind it)
+        host_dt = time.perf_counter() - t1  # host enqueue time of the leg (the device runs behind it) ...
+        host_wait = pipe.throttle_wait_s - w0  # ... of which the host spent this much waiting in the pipeline's run-ahead throttle
         barrier()
         sdt = time.perf_counter() - t1
         if world > 1:
@@ -414,7 +429,11 @@ def main():
             torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
             sdt = float(tm.item())
         sustained = {"steps": args.sustained_steps, "value": round(world * B * args.sustained_steps / sdt, 2), "unit": "images/s",
-                     "ms_per_step": round(sdt / args.sustained_steps * 1e3, 4), "host_enqueue_ms_per_step": round(host_dt / args.sustained_steps * 1e3, 4)}
+                     "ms_per_step": round(sdt / args.sustained_steps * 1e3, 4), "host_enqueue_ms_per_step": round(host_dt / args.sustained_steps * 1e3, 4),
+                     # the enqueue time split: waiting for the device in FeaturePipeline's run_ahead throttle / actual host work (Python,
+                     # ctypes, autograd, launch calls): the second is what a busy host or eight ranks per node must afford per step
+                     "host_throttle_wait_ms_per_step": round(host_wait / args.sustained_steps * 1e3, 4),
+                     "host_work_ms_per_step": round((host_dt - host_wait) / args.sustained_steps * 1e3, 4)}
 
     # ---------------- optional PCIe-inclusive leg (never `value`): the same steps fed from HOST memory
     h2d = None

@@ -92,6 +92,12 @@ __device__ __forceinline__ void gemm_epilogue(const ARGS& p, f32x4_t (&acc)[NT][
     for (int e = 0; e < 4; ++e)
       if (ncol + e < p.N) bias4[e] = p.bias[ncol + e];
   }
+  // An unconditional use right here: the compiler waits for the bias loads ONCE, before any store is issued.  Their only other
+  // uses sit inside the row loop's `m < M` regions, and its wait-count pass must assume that a skipped row leaves them pending —
+  // it then re-waits with s_waitcnt vmcnt(0) at every row group, i.e. for all the stores issued so far (seen in the ISA of every
+  // tile kernel in round 4: one store round trip per row group).
+#pragma unroll
+  for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(bias4[e]));
 
 #pragma unroll
   for (int h = 0; h < MT / 2; ++h) {
@@ -326,7 +332,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
   after_first_loads();
   float bias8[8];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { bias8[e] = __builtin_bit_cast(float, bias_a[e]); bias8[4 + e] = __builtin_bit_cast(float, bias_b[e]); }
+  for (int e = 0; e < 4; ++e) { bias8[e] = u2f(bias_a[e]); bias8[4 + e] = u2f(bias_b[e]); }
 #pragma unroll
   for (int u = 0; u < MT; ++u) {
     // (straight-line code: without the fence the scheduler pulls the LDS round trips and residual loads of later units forward until
@@ -354,8 +360,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
       if (RES) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[it][e] += __builtin_bit_cast(float, rpre[it][0][e]);
-          v[it][4 + e] += __builtin_bit_cast(float, rpre[it][1][e]);
+          v[it][e] += u2f(rpre[it][0][e]);
+          v[it][4 + e] += u2f(rpre[it][1][e]);
         }
       }
     }
@@ -363,10 +369,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       if (F32OUT) {
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, v[it][0]), __builtin_bit_cast(uint32_t, v[it][1]),
-                                                       __builtin_bit_cast(uint32_t, v[it][2]), __builtin_bit_cast(uint32_t, v[it][3])}, r_o32, ro[it].out, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, v[it][4]), __builtin_bit_cast(uint32_t, v[it][5]),
-                                                       __builtin_bit_cast(uint32_t, v[it][6]), __builtin_bit_cast(uint32_t, v[it][7])}, r_o32, ro[it].out, 16, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][0]), f2u(v[it][1]), f2u(v[it][2]), f2u(v[it][3])}, r_o32, ro[it].out, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][4]), f2u(v[it][5]), f2u(v[it][6]), f2u(v[it][7])}, r_o32, ro[it].out, 16, 0);
       }
       if (PAIR) {
         uint32_t hw[4], lw[4];

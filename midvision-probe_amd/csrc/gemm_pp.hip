@@ -187,7 +187,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
     }
   };
 
-  auto stage_a = [&](int par, int kt, int half) {  // this wave's two pieces of HA<half> of k-step kt
+  // ``live`` = false: the same instructions on a zero-sized resource (every lane out of range: zeros land in the LDS destination, no
+  // memory is read) and no state advanced — what the prefetch hook issues when there is no next tile, so that the epilogue's
+  // instruction stream holds the same number of memory operations either way (the compiler's counted waits stay exact, see the hook).
+  auto stage_a = [&](int par, int kt, int half, bool live = true) {  // this wave's two pieces of HA<half> of k-step kt
 #if MVP_PP_ABLATE != 2
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -196,13 +199,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
         const int yy = (cv_yx[half * 2 + e] >> 16) - 0x4000 + ct_ky[half], xx = (cv_yx[half * 2 + e] & 0xffff) - 0x4000 + ct_kx[half];
         const bool ok = ((unsigned)yy < (unsigned)p.cH) && ((unsigned)xx < (unsigned)p.cW);
         const int off = cv_img[half * 2 + e] + (((yy >> p.cup) * cWs + (xx >> p.cup)) * p.lda + ct_c0[half]) * 2;
-        lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, a_bytes, smem + par * PP_BUF_B + q * 1024, ok ? off : 0x7fffff80, 0);
+        lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, live ? a_bytes : 0u, smem + par * PP_BUF_B + q * 1024, ok ? off : 0x7fffff80, 0);
       } else {
-        lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, 0x7fffff00u, smem + par * PP_BUF_B + q * 1024, a_voff[half * 2 + e], kt * KSTEP_A);
+        lds_dma16(piece_lo(ILVA, q) ? pa_lo : pa_hi, live ? 0x7fffff00u : 0u, smem + par * PP_BUF_B + q * 1024, a_voff[half * 2 + e], kt * KSTEP_A);
       }
     }
 #endif
-    if (CONV) {  // every half is staged in increasing k order: advance its running tap position
+    if (CONV && live) {  // every half is staged in increasing k order: advance its running tap position
       ct_c0[half] += 32;
       if (ct_c0[half] >= p.cC) {
         ct_c0[half] = 0;
@@ -210,12 +213,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
       }
     }
   };
-  auto stage_w = [&](int par, int kt) {  // this wave's four pieces of HB of k-step kt
+  auto stage_w = [&](int par, int kt, bool live = true) {  // this wave's four pieces of HB of k-step kt
 #if MVP_PP_ABLATE != 2
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int q = 4 * wave + e;
-      lds_dma16(piece_lo(ILVW, q) ? pw_lo : pw_hi, 0x7fffff00u, smem + par * PP_BUF_B + PP_TILE_B + q * 1024, w_voff[e], kt * KSTEP_W);
+      lds_dma16(piece_lo(ILVW, q) ? pw_lo : pw_hi, live ? 0x7fffff00u : 0u, smem + par * PP_BUF_B + PP_TILE_B + q * 1024, w_voff[e], kt * KSTEP_W);
     }
 #endif
   };
@@ -412,13 +415,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
     const bool has_next = nbid < tiles;
     const bool pre = has_next && wide != 0 && MVP_PP_PREFETCH;
     if (has_next) setup_tile(nbid);
-    // ahead of the epilogue's stores (vmcnt retires in order), behind its first loads: the next tile's first k-step into buffer 0
+    // Ahead of the epilogue's stores (vmcnt retires in order), behind its first loads: the next tile's first k-step into buffer 0.
+    // Issued UNCONDITIONALLY — without a next tile as 8 dead pieces (zero-sized resource) into buffer 1, which nothing uses then: were
+    // the 8 LDS-DMA instructions under a branch, the compiler's wait for the epilogue's first loads (bias, first residual rows; issued
+    // BEFORE this hook) would have to assume the path without them, i.e. leave fewer operations in flight than this path has issued
+    // behind those loads — and so wait for the prefetch itself, exposing exactly the latency it is there to hide.
     auto prefetch = [&]() {
-      if (pre) {
-        stage_a(0, 0, 0);
-        stage_w(0, 0);
-        stage_a(0, 0, 1);
-      }
+      const int par = pre ? 0 : 1;
+      stage_a(par, 0, 0, pre);
+      stage_w(par, 0, pre);
+      stage_a(par, 0, 1, pre);
     };
     char* const scratch = smem + (pre ? PP_BUF_B : 0);
     // (an opaque per-tile copy of the lane id: the epilogue's per-lane constants would otherwise be hoisted out of the tile loop and

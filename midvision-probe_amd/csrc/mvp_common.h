@@ -46,6 +46,11 @@ __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, 
   const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// Bit pattern <-> float through a SCALAR.  (ROCm 7.2's clang miscompiles __builtin_bit_cast(float, vec[e]) written directly on an
+// element of an ext_vector: every e yields element 0 — the optimiser then narrows a 16-byte load to its first dword.  Passing the
+// element by value makes it a scalar first.)
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ uint32_t pack2(uint16_t a, uint16_t b) {
   return (uint32_t)a | ((uint32_t)b << 16);
 }

@@ -41,6 +41,7 @@ import collections
 import contextlib
 import itertools
 import os
+import time
 import weakref
 from typing import Iterable, Iterator, Tuple
 
@@ -323,6 +324,7 @@ class FeaturePipeline:
             graphs = (env != "0") if env is not None else not _multi_rank()
         self.graphs = bool(graphs) and depth > 1 and bool(getattr(model, "graph_safe", False))
         self._warned_eager_span = False
+        self.throttle_wait_s = 0.0  # wall time the host has spent waiting in the ``run_ahead`` throttle (not work: the device was behind)
         self._graphs = {}  # (slot, shape, dtype, training, engine id, group) -> dict(calls, graph, static_in, feats, deferred)
         self._stage = {}   # (slot, shape, dtype) -> stacked input buffer of eager grouped forwards
         self._static = {}  # (slot, shape, dtype) -> static input buffer of that slot's graphs
@@ -545,7 +547,9 @@ class FeaturePipeline:
         if self.free_slots() <= 0:
             raise RuntimeError(f"{self.depth} forwards already in flight: call next() first")
         if self.run_ahead > 0 and len(self._issued) >= self.run_ahead:
+            t0 = time.perf_counter()
             self._issued.popleft().synchronize()  # host waits for the forward issued ``run_ahead`` submissions ago
+            self.throttle_wait_s += time.perf_counter() - t0  # (bench.py tells host WORK from this wait)
         if self.depth == 1:
             feats = _extract(self.model, batches[0])
             if self.run_ahead > 0 and batches[0].is_cuda:

@@ -168,9 +168,26 @@ def main():
                               + f"   total={mean[0, ph].sum():.0f}|{mean[1, ph].sum():.0f}", flush=True)
                     # per TILE: what precedes the main loop (cold prologue of the first tile, tile switch of the others), the main loop, the epilogue
                     pro, loop, epi = ((raw[:, :, c] / per_wg.view(grid, 1)).mean().item() for c in (10, 11, 12))
-                    life = (raw[:, :, 14] - raw[:, :, 13]).mean().item()
+                    lifes = (raw[:, 0, 14] - raw[:, 0, 13])
+                    life = lifes.mean().item()
                     print(f"   per tile: prologue / tile switch {pro:.0f} cycles, main loop {loop:.0f}, epilogue {epi:.0f}; workgroup lifetime {life:.0f} cycles "
                           f"for {per_wg.mean().item():.2f} tiles", flush=True)
+                    # what bounds the launch is the SLOWEST workgroup: lifetime spread, and the spread of the end times on the 100 MHz
+                    # real-time counter (comparable across XCDs, unlike s_memtime)
+                    full = per_wg == per_wg.max()
+                    lf = lifes[full]
+                    ends = raw[:, 0, 15]
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        lst.mvp_gemm_pp(C.byref(g), st)
+                    e1.record(); torch.cuda.synchronize()
+                    wall = e0.elapsed_time(e1) / 10 * 1e3
+                    raw2 = dbg.view(grid, 2, 16).double()
+                    ends = raw2[:, 0, 15]
+                    print(f"   lifetime of the workgroups with {int(per_wg.max().item())} tiles: min {lf.min().item():.0f}  median {lf.median().item():.0f}  max {lf.max().item():.0f} cycles "
+                          f"(max / mean {lf.max().item() / lf.mean().item():.3f}); end times spread over {(ends.max() - ends.min()).item() * 0.01:.1f} us; "
+                          f"launch wall time (stamp build) {wall:.1f} us = {life / wall / 1e3:.2f} GHz if the mean lifetime filled it", flush=True)
         return 0
 
     # ------------------------------------------------------------------ timing
