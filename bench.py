@@ -142,7 +142,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (reference default batch_size: 16)")
     ap.add_argument("--image-size", default="224", help="S or HxW (480x640 = BASELINE config #2)")
-    ap.add_argument("--precision", default=os.environ.get("MVP_PRECISION", "bf16x3"), choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("MVP_PRECISION", "bf16x3"), choices=["bf16x3", "f16x2", "bf16"])
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: batches start in host memory and go through mvp.prefetch.DevicePrefetcher (not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-oracle steps (~1.8 s each at B=16 on 16 cores: ~11 s bounded sample)")

@@ -35,6 +35,13 @@ extern "C" {
 
 #define MVP_PREC_BF16 1   /* one bf16 MFMA pass                              */
 #define MVP_PREC_BF16X3 3 /* three passes (split bf16), ~fp32 operand accuracy */
+#define MVP_PREC_F16X2 2  /* (ABI 6, opt-in) TWO passes per contraction of mvp_gemm_bias_act_res / mvp_gemm_pp (plain linear GEMMs only):
+                             the activation operand is a pair hi = fp16(a), lo = bf16(a - hi) (what LayerNorm / attention / a GEMM epilogue
+                             write under their out_f16 / out_f16_col0 switches), the weight operand holds hi = fp16(w), lo = bf16(w) — two
+                             roundings of the SAME value — and the product runs as  a_lo . bf16(w)  (bf16 MFMA)  +  a_hi . fp16(w)  (f16
+                             MFMA), fp32 accumulate.  Operand error: the activation to 2^-20, the weight to 2^-12 (one fp16 rounding of a frozen
+                             weight).  2/3 of the matrix-pipe work of BF16X3 on a chip whose clock is held down by exactly that work
+                             (the large-M kernel: -19 % time); measured feature error in tests/test_gpu_kernels.py (ViT goldens).      */
 
 #define MVP_ACT_NONE 0
 #define MVP_ACT_GELU 1 /* exact erf GELU (torch nn.GELU default)            */
@@ -155,8 +162,8 @@ typedef struct {
    * [rows][N / 32][hi 32 | lo 32] with row stride ldob (2 * N when dense), out_lo is ignored, N % 32 == 0 — the A operand of a following
    * large-M GEMM (fc1 -> fc2).  Any kernel of mvp_gemm_bias_act_res writes it.                                                        */
   int out_pair_layout;
-  /* --- mixed 16-bit forms inside the bf16-pair output (ABI 6): out_f16_col0 > 0 (a multiple of 64, MVP_PREC_BF16X3, out_hi and a lo
-   * half required): columns >= out_f16_col0 are written as hi = fp16(v) (round to nearest even), lo = bf16(v - hi) instead of
+  /* --- mixed 16-bit forms inside the bf16-pair output (ABI 6): out_f16_col0 > 0 (a multiple of 64; or -1: every column; MVP_PREC_BF16X3 / F16X2,
+   * out_hi and a lo half required): columns >= out_f16_col0 are written as hi = fp16(v) (round to nearest even), lo = bf16(v - hi) instead of
    * hi = bf16(v), lo = bf16(v - hi) — the V third of the fused qkv projection (out_f16_col0 = 2 * H * 64), which the attention
    * kernel multiplies with probabilities held as ONE fp16 value (mvp_attention_args.v_format).  Same 2 + 2 bytes, same arrays and
    * layouts; |v - hi - lo| <= 2^-20 |v|.  Every kernel of mvp_gemm_bias_act_res / mvp_gemm_pp writes it (not stream-K).        */
@@ -194,6 +201,7 @@ typedef struct {
   float eps;
   int out_layout;                     /* MVP_PAIR_SEPARATE, or MVP_PAIR_A_ILV32 (1): out_hi is ONE [M][C / 32][hi 32 | lo 32] array (row stride
                                          2 * C), out_lo ignored, C % 32 == 0 — the A operand of the large-M GEMM (mvp_gemm_args.pair_layout) */
+  int out_f16;                        /* (ABI 6) 1: the pair is written as hi = fp16(y), lo = bf16(y - hi): the activation operand of MVP_PREC_F16X2 */
 } mvp_layernorm_args;
 int mvp_layernorm_fwd(const mvp_layernorm_args*, void* stream);
 
@@ -220,6 +228,7 @@ typedef struct {
                        instead of three and no hi / lo split of P on the vector pipe (the kernel is VALU-bound); the online softmax
                        rescales its running maximum only when it rises by more than 2^6.  Q.K^T keeps its three products either way.
                        Relative error of the output: ~2^-12 per probability (random, averaged over the keys) instead of 2^-17.        */
+  int out_f16;      /* (ABI 6) 1: the output pair is written as hi = fp16(o), lo = bf16(o - hi): the activation operand of a MVP_PREC_F16X2 proj GEMM */
 } mvp_attention_args;
 #define MVP_ATT_V_BF16_PAIR 0
 #define MVP_ATT_V_F16 1

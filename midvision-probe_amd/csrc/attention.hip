@@ -59,7 +59,6 @@ namespace {
 #endif
 constexpr int TILE = 64 * 128;  // one 64-key x 64-d bf16 tile
 constexpr float ATT_DEFER = 6.0f;  // VF16: the running maximum moves only when a row's maximum rises by more than this (exp2 units)
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
 template <int SPLIT>
 struct AttnState {
@@ -270,8 +269,13 @@ __device__ __forceinline__ void attn_store(AttnState<SPLIT>& st, const mvp_atten
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint32_t h01, l01, h23, l23;
-      split2_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
-      split2_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
+      if (p.out_f16) {  // hi = fp16, lo = bf16: the activation operand of a two-product (MVP_PREC_F16X2) proj GEMM
+        split2_f16_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
+        split2_f16_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
+      } else {
+        split2_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
+        split2_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
+      }
       if (ilv) {
         const size_t o = ob + (dt >> 1) * 64 + (dt & 1) * 16;
         *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
@@ -481,6 +485,6 @@ extern "C" int mvp_attention_fwd(const mvp_attention_args* a, void* stream) {
     if (a->v_format != MVP_ATT_V_BF16_PAIR) return MVP_EINVAL;
     return launch_attention<3>(a, (hipStream_t)stream);
   }
-  if (a->precision != MVP_PREC_BF16 || a->v_format != MVP_ATT_V_BF16_PAIR) return MVP_EINVAL;
+  if (a->precision != MVP_PREC_BF16 || a->v_format != MVP_ATT_V_BF16_PAIR || a->out_f16) return MVP_EINVAL;
   return launch_attention<1>(a, (hipStream_t)stream);
 }

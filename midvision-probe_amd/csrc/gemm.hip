@@ -60,7 +60,7 @@ template <int BM, int BN, int BK, int SPLIT, int NSTAGE, bool CONV, bool EXT, bo
 __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   static_assert(!(KSPLIT && (CONV || EXT)), "split-K is compiled for the plain linear GEMMs only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NARR = (SPLIT == 3) ? 2 : 1;
+  constexpr int NARR = (SPLIT >= 2) ? 2 : 1;  // SPLIT 3: bf16 pairs, three products; 2 (MVP_PREC_F16X2): fp16 hi + bf16 lo activations, two products
   constexpr int ROWB = BK * 2;            // bytes per LDS row
   constexpr int CH = ROWB / 16;           // 16-byte chunks per row (8 or 4)
   constexpr int RPP = 1024 / ROWB;        // rows per 1-KiB LDS-DMA piece (8 or 16)
@@ -123,10 +123,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
   // (the resource descriptors are rebuilt from these base pointers inside the lambda: a lambda capturing a variable of the opaque
   // __amdgpu_buffer_rsrc_t type makes the HOST pass drop the whole kernel template without a diagnostic — ROCm 7.2 clang)
   mvp_bf16* const pa_hi = (mvp_bf16*)p.a_hi + a_base;
-  mvp_bf16* const pa_lo = (mvp_bf16*)(SPLIT == 3 ? p.a_lo : p.a_hi) + a_base;
+  mvp_bf16* const pa_lo = (mvp_bf16*)(SPLIT >= 2 ? p.a_lo : p.a_hi) + a_base;
   const size_t w_base = (size_t)n0 * p.ldw;
   mvp_bf16* const pw_hi = (mvp_bf16*)p.w_hi + w_base;
-  mvp_bf16* const pw_lo = (mvp_bf16*)(SPLIT == 3 ? p.w_lo : p.w_hi) + w_base;
+  mvp_bf16* const pw_lo = (mvp_bf16*)(SPLIT >= 2 ? p.w_lo : p.w_hi) + w_base;
   int a_voff[APASS], w_voff[BN / (NW * RPP)];
 #pragma unroll
   for (int ps = 0; ps < APASS; ++ps) {
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
         const int off = ((((cvb[ps] * cHs + (yy >> p.cup)) * cWs + (xx >> p.cup)) * p.lda) + ct_c0 + csrc) * 2;
         const int voff = ok ? off : 0x7fffff80;  // padding tap: beyond num_records -> the load returns zeros
         lds_dma16(pa_hi, a_bytes, base + r * ROWB, voff, 0);
-        if (SPLIT == 3) lds_dma16(pa_lo, a_bytes, base + A_BYTES + r * ROWB, voff, 0);
+        if (SPLIT >= 2) lds_dma16(pa_lo, a_bytes, base + A_BYTES + r * ROWB, voff, 0);
       } else {
         lds_dma16(pa_hi, a_bytes, base + r * ROWB, a_voff[ps], k0b);
-        if (SPLIT == 3) lds_dma16(pa_lo, a_bytes, base + A_BYTES + r * ROWB, a_voff[ps], k0b);
+        if (SPLIT >= 2) lds_dma16(pa_lo, a_bytes, base + A_BYTES + r * ROWB, a_voff[ps], k0b);
       }
     }
     if (CONV) {  // tiles are staged in increasing kt order: advance the running tap position
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
     for (int ps = 0; ps < BN / (NW * RPP); ++ps) {
       const int r = ps * NW * RPP + wave * RPP;
       lds_dma16(pw_hi, 0x7fffff00u, wb + r * ROWB, w_voff[ps], k0b);
-      if (SPLIT == 3) lds_dma16(pw_lo, 0x7fffff00u, wb + W_BYTES + r * ROWB, w_voff[ps], k0b);
+      if (SPLIT >= 2) lds_dma16(pw_lo, 0x7fffff00u, wb + W_BYTES + r * ROWB, w_voff[ps], k0b);
     }
   };
 
@@ -205,12 +205,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         a_hi[j] = *(const bf16x8_t*)(ab + j * 16 * ROWB + coff);
-        if (SPLIT == 3) a_lo[j] = *(const bf16x8_t*)(ab + A_BYTES + j * 16 * ROWB + coff);
+        if (SPLIT >= 2) a_lo[j] = *(const bf16x8_t*)(ab + A_BYTES + j * 16 * ROWB + coff);
       }
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         w_hi[i] = *(const bf16x8_t*)(wb + i * 16 * ROWB + coff);
-        if (SPLIT == 3) w_lo[i] = *(const bf16x8_t*)(wb + W_BYTES + i * 16 * ROWB + coff);
+        if (SPLIT >= 2) w_lo[i] = *(const bf16x8_t*)(wb + W_BYTES + i * 16 * ROWB + coff);
       }
 #if MVP_ABLATE == 1
 #pragma unroll
@@ -223,6 +223,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
+          if (SPLIT == 2) {  // MVP_PREC_F16X2: a_lo . bf16(w), then a_hi . fp16(w) (the order gemm_pp.hip uses)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_lo[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w_hi[i]), __builtin_bit_cast(f16x8_t, a_hi[j]), acc[i][j], 0, 0, 0);
+            continue;
+          }
           if (SPLIT == 3) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_hi[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_lo[j], acc[i][j], 0, 0, 0);
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
 
 template <int BM, int BN, int BK, int SPLIT, int NSTAGE, int NW = 4, int WNW = 2>
 constexpr int gemm_smem() {
-  constexpr int NARR = (SPLIT == 3) ? 2 : 1;
+  constexpr int NARR = (SPLIT >= 2) ? 2 : 1;
   constexpr int stages = NSTAGE * (BM + BN) * BK * 2 * NARR;
   constexpr int epi = NW * 32 * (BN / WNW + 4) * 4;
   return stages > epi ? stages : epi;
@@ -434,7 +439,7 @@ extern "C" int mvp_gemm_streamk(const mvp_gemm_args* a, void* stream);  // gemm_
 // prologue + epilogue per round, so: long K from 128 tiles on, short K from 200 tiles on when the rounds are >= 80 % full.
 // MVP_GEMM_PP = 0 / 1 (diagnostic override): never / whenever the kernel supports the arguments.
 static bool pp_takes(const mvp_gemm_args* a) {
-  if (a->precision != MVP_PREC_BF16X3 || a->splitk > 1 || (a->K & 31) || a->K < 64) return false;
+  if ((a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2) || a->splitk > 1 || (a->K & 31) || a->K < 64) return false;
   static const int env = [] { const char* e = getenv("MVP_GEMM_PP"); return e ? atoi(e) : -1; }();
   if (a->conv) {
     // convolutions (the DPT probe's 3x3 layers at 8x the token grid: M = 200 704 pixels, K = 4608 / 2304): the large-M kernel with
@@ -460,8 +465,8 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (a->splitk == MVP_GEMM_STREAMK) return a->out_f16_col0 ? MVP_EINVAL : mvp_gemm_streamk(a, stream);
   if (a->pair_layout < 0 || a->pair_layout > MVP_PAIR_ILV32) return MVP_EINVAL;
   if (a->out_pair_layout != MVP_PAIR_SEPARATE &&
-      (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31) || a->precision != MVP_PREC_BF16X3)) return MVP_EINVAL;
-  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < 0 || (a->out_f16_col0 & 63) || a->precision != MVP_PREC_BF16X3 || !a->out_hi ||
+      (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31) || (a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2))) return MVP_EINVAL;
+  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < -1 || (a->out_f16_col0 > 0 && (a->out_f16_col0 & 63)) || (a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2) || !a->out_hi ||
                                (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE) || a->splitk > 1))
     return MVP_EINVAL;
   if (a->M > 0 && a->N > 0 && (a->out_f32 || a->out_hi) && pp_takes(a)) return mvp_gemm_pp(a, stream);
@@ -471,8 +476,17 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
     if (!(a && !a->conv && a->M > 0 && a->N > 0 && a->K > 0 && (a->K & 31) == 0 && a->precision == MVP_PREC_BF16X3 && a->splitk <= 1)) return MVP_EINVAL;
   }
   if ((a->lda & 7) || (a->ldw & 7)) return MVP_EINVAL;  // 16-byte aligned rows for LDS-DMA
-  if (a->precision == MVP_PREC_BF16X3 && (!a->a_lo || !a->w_lo)) return MVP_EINVAL;
-  if (a->precision != MVP_PREC_BF16 && a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
+  if ((a->precision == MVP_PREC_BF16X3 || a->precision == MVP_PREC_F16X2) && (!a->a_lo || !a->w_lo)) return MVP_EINVAL;
+  if (a->precision != MVP_PREC_BF16 && a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2) return MVP_EINVAL;
+  if (a->precision == MVP_PREC_F16X2) {
+    // the two-product mode (opt-in): plain linear GEMMs of the ViT blocks, K % 64 == 0; a reduced tile rule (three shapes)
+    if (a->conv || a->splitk > 1 || (a->K & 63) || a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) return MVP_EINVAL;
+    if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
+    hipStream_t s2 = (hipStream_t)stream;
+    if (a->N >= 1024) return launch_gemm<128, 128, 64, 2, 1, false, 8>(a, s2);
+    const long t64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64);
+    return t64 <= 1280 ? launch_gemm<64, 64, 64, 2, 1>(a, s2) : launch_gemm<128, 64, 64, 2, 1>(a, s2);
+  }
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool x3 = a->precision == MVP_PREC_BF16X3;

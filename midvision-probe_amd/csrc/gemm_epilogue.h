@@ -194,7 +194,7 @@ __device__ __forceinline__ void gemm_epilogue(const ARGS& p, f32x4_t (&acc)[NT][
           for (int e = 0; e < 4; ++e) v[e] *= keep[e];  // (out_f32 above stayed un-gated)
         }
         uint32_t h01, l01, h23, l23;
-        if (p.out_f16_col0 > 0 && ncol >= p.out_f16_col0) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv (4 columns: all in or all out)
+        if (p.out_f16_col0 != 0 && ncol >= p.out_f16_col0) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv / every column (-1); 4 columns: all in or all out
           split2_f16_bf16(v[0], v[1], h01, l01);
           split2_f16_bf16(v[2], v[3], h23, l23);
         } else {
@@ -285,7 +285,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
   const __amdgpu_buffer_rsrc_t r_bias = rsrc(p.bias), r_res = rsrc(RES ? (const void*)p.residual : nullptr), r_gate = rsrc(GATE ? (const void*)p.relu_mask : nullptr);
   const __amdgpu_buffer_rsrc_t r_o32 = rsrc(F32OUT ? (const void*)p.out_f32 : nullptr), r_ohi = rsrc(PAIR ? (const void*)p.out_hi : nullptr);
   const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;
-  const bool f16_cols = PAIR && p.out_f16_col0 > 0 && (n0 + wn0) >= p.out_f16_col0;  // this wave's 64 columns take the fp16-hi form
+  const bool f16_cols = PAIR && p.out_f16_col0 != 0 && (n0 + wn0) >= p.out_f16_col0;  // this wave's 64 columns take the fp16-hi form (-1: every column)
   const __amdgpu_buffer_rsrc_t r_olo = rsrc(PAIR ? (oilv ? (const void*)p.out_hi : (const void*)p.out_lo) : nullptr);  // interleaved: the lo half sits 64 bytes behind the hi half
   const int lo_soff = oilv ? 64 : 0;
   const int ob = col_ok ? ncol * 4 : SENT;

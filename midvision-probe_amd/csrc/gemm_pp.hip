@@ -38,7 +38,7 @@
 #include "gemm_epilogue.h"
 
 #ifndef MVP_PP_ABLATE
-#define MVP_PP_ABLATE 0  // diagnostic builds (tools/pp_bench.py): 1 = no MFMA, 2 = no LDS-DMA in the loop, 3 = no fragment reads
+#define MVP_PP_ABLATE 0  // diagnostic builds (tools/pp_bench.py): 1 = no MFMA, 2 = no LDS-DMA in the loop, 3 = no fragment reads, 4 = two MFMAs per fragment pair
 #endif
 // MVP_PP_STAMP 1 (diagnostic build only): s_memtime stamps around the five segments of every phase (issue of reads + LDS-DMA, the
 // counted waits, barrier 1, the MFMA cluster, barrier 2), summed per phase type in SGPRs by waves 0 and 4 of every workgroup and
@@ -95,9 +95,14 @@ constexpr int PP_SMEM = 2 * PP_BUF_B;    // two k-step buffers = 128 KiB
 //   * no workgroup exit / dispatch / kernel-argument load between the tiles of a CU.
 // Only the wide epilogues (no other loads in flight but the residual's) prefetch across the epilogue; the generic epilogue (masks, second
 // residuals: the DPT convolutions, K >= 1152 there) keeps its 70 KB scratch at the start of LDS and re-runs the cold prologue per tile.
-template <bool ILVA, bool ILVW, bool EXT, bool CONV = false>
+// F16X2 (MVP_PREC_F16X2): two products per fragment pair instead of three — the activation pair is hi = fp16, lo = bf16, the weight
+// "pair" holds fp16(w) and bf16(w): acc += a_lo . bf16(w) (bf16 MFMA), then acc += a_hi . fp16(w) (f16 MFMA).  Same arrays, layouts,
+// staging and fragment reads (the halves are 16-bit either way); per 32-deep k-step lo product first, then hi, k ascending — the
+// order the tile kernels use, so the two families stay bit-identical in this mode too.
+template <bool ILVA, bool ILVW, bool EXT, bool CONV = false, bool F16X2 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   static_assert(!(CONV && ILVA), "the convolution reads separate hi / lo activation arrays");
+  static_assert(!(F16X2 && (CONV || EXT)), "the two-product mode serves the plain linear GEMMs of the ViT blocks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256, BN = 256, WM = 128, WN = 64, MT = 8, NT = 4;
 #if MVP_PP_STAMP
@@ -267,7 +272,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4_t c = acc[i][half * 4 + j];
+        if constexpr (F16X2) {
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_lo[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w_hi[i]), __builtin_bit_cast(f16x8_t, a_hi[j]), c, 0, 0, 0);
+          acc[i][half * 4 + j] = c;
+          continue;
+        }
+#if MVP_PP_ABLATE != 4  // (4: two products per fragment pair instead of three — what a two-product precision mode would issue; wrong results, timing only)
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_hi[j], c, 0, 0, 0);
+#endif
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_lo[j], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[i], a_hi[j], c, 0, 0, 0);
         acc[i][half * 4 + j] = c;
@@ -512,6 +525,24 @@ inline int pp_cu_count() {
   return n;
 }
 
+inline int pp_grid(const mvp_gemm_args* a) {
+  const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+  // persistent grid: one workgroup per CU (128 KB of LDS each), tiles dealt round by round; MVP_PP_PERSIST=0 (diagnostic): one tile
+  // per workgroup, the pre-round-4 launch.  (A multiple of 8 keeps a workgroup's tiles on one XCD slice of the region order.)
+  static const int persist = [] { const char* e = getenv("MVP_PP_PERSIST"); return (e ? atoi(e) : 1) && !MVP_PP_NOLOOP; }();
+  const int cus = pp_cu_count() & ~7;
+  return (persist && cus >= 8 && tiles > cus) ? cus : tiles;
+}
+
+template <bool ILVA, bool ILVW>
+int launch_pp_f16x2(const mvp_gemm_args* a, hipStream_t s) {  // MVP_PREC_F16X2: plain epilogues only (the caller checked)
+  static int configured = (int)hipFuncSetAttribute((const void*)gemm_pp_kernel<ILVA, ILVW, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
+  if (configured != 0) return MVP_ELAUNCH;
+  hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, false, false, true>), dim3(pp_grid(a)), dim3(512), PP_SMEM, s, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
 template <bool ILVA, bool ILVW, bool CONV = false>
 int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
   static int configured = [] {
@@ -520,12 +551,7 @@ int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
     return e;
   }();
   if (configured != 0) return MVP_ELAUNCH;
-  const int tiles = ((a->M + 255) / 256) * ((a->N + 255) / 256);
-  // persistent grid: one workgroup per CU (128 KB of LDS each), tiles dealt round by round; MVP_PP_PERSIST=0 (diagnostic): one tile
-  // per workgroup, the pre-round-4 launch.  (A multiple of 8 keeps a workgroup's tiles on one XCD slice of the region order.)
-  static const int persist = [] { const char* e = getenv("MVP_PP_PERSIST"); return (e ? atoi(e) : 1) && !MVP_PP_NOLOOP; }();
-  const int cus = pp_cu_count() & ~7;
-  const int grid = (persist && cus >= 8 && tiles > cus) ? cus : tiles;
+  const int grid = pp_grid(a);
   // (the gated-input-gradient combination has a wide epilogue of its own in the plain instantiation)
   const bool ext = (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) && gemm_epilogue_wide_variant(*a) != 6;
   if (ext)
@@ -550,16 +576,22 @@ extern "C" int mvp_gemm_pp(const mvp_gemm_args* a, void* stream) {
     if ((a->cH & ((1 << a->cup) - 1)) || (a->cW & ((1 << a->cup) - 1)) || a->cH >= 0x4000 || a->cW >= 0x4000 || a->cpad >= 0x2000) return MVP_EINVAL;
     if ((int64_t)(a->M / (a->cHo * a->cWo)) * (a->cH >> a->cup) * (a->cW >> a->cup) * a->lda * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   }
-  if ((a->lda & 7) || (a->ldw & 7) || a->precision != MVP_PREC_BF16X3) return MVP_EINVAL;
+  if ((a->lda & 7) || (a->ldw & 7) || (a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2)) return MVP_EINVAL;
+  const bool f16x2 = a->precision == MVP_PREC_F16X2;
+  if (f16x2 && (a->conv || a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi)) return MVP_EINVAL;
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   if (a->out_pair_layout != MVP_PAIR_SEPARATE && (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31))) return MVP_EINVAL;
-  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < 0 || (a->out_f16_col0 & 63) || !a->out_hi || (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE))) return MVP_EINVAL;
+  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < -1 || (a->out_f16_col0 > 0 && (a->out_f16_col0 & 63)) || !a->out_hi || (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE))) return MVP_EINVAL;
   // 32-bit per-lane byte offsets: 256 tile rows of the widest supported row must stay below 2 GiB
   if ((int64_t)256 * a->lda * 2 >= 0x7fffff00ll || (int64_t)256 * a->ldw * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
 #ifdef MVP_PP_ONE  // diagnostic builds: only the interleaved-operand instantiation (fast compiles of experiments)
-  return (ilva && ilvw && !a->conv) ? launch_pp<true, true>(a, st) : MVP_EINVAL;
+  return (ilva && ilvw && !a->conv && !f16x2) ? launch_pp<true, true>(a, st) : MVP_EINVAL;
 #else
+  if (f16x2) {
+    if (ilva) return ilvw ? launch_pp_f16x2<true, true>(a, st) : launch_pp_f16x2<true, false>(a, st);
+    return ilvw ? launch_pp_f16x2<false, true>(a, st) : launch_pp_f16x2<false, false>(a, st);
+  }
   if (a->conv) return ilvw ? launch_pp<false, true, true>(a, st) : launch_pp<false, false, true>(a, st);
   if (ilva) return ilvw ? launch_pp<true, true>(a, st) : launch_pp<true, false>(a, st);
   return ilvw ? launch_pp<false, true>(a, st) : launch_pp<false, false>(a, st);

@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
       const size_t o = (size_t)row * p.C + c * 8;
       uint32_t h[4], l[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) split2_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
+      for (int e = 0; e < 4; ++e) {
+        if (p.out_f16) split2_f16_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
+        else split2_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
+      }
       if (p.out_layout == MVP_PAIR_A_ILV32) {  // one array, hi | lo interleaved per 32 columns (an 8-element chunk never straddles a block)
         const size_t oi = (size_t)row * 2 * p.C + ilv32_col(c * 8);
         *(u32x4_t*)(p.out_hi + oi) = u32x4_t{h[0], h[1], h[2], h[3]};

@@ -18,7 +18,11 @@ from mvp.vit import parse_precision
 
 
 def _precision(p):
-    return parse_precision(p or bb.default_precision())
+    pr = parse_precision(p or bb.default_precision())
+    # 'f16x2' is a mode of the frozen ViT blocks' GEMMs (two products against frozen weights); the trained probe keeps three
+    from mvp import lib
+
+    return lib.PREC_BF16X3 if pr == lib.PREC_F16X2 else pr
 
 
 class SurfaceNormalHead(nn.Module):

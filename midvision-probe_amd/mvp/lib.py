@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("MVP_LIB") or os.path.join(os.path.dirname(_HERE), "cs
 
 PREC_BF16 = 1
 PREC_BF16X3 = 3
+PREC_F16X2 = 2  # two products per GEMM contraction (fp16 hi + bf16 lo activations, fp16 / bf16 roundings of the weights): mvp_hip.h
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BICUBIC = 0, 1, 2
 PAIR_SEPARATE, PAIR_A_ILV32, PAIR_W_ILV32 = 0, 1, 2  # mvp_gemm_args.pair_layout (bit flags)
@@ -60,12 +61,12 @@ class GemmArgs(C.Structure):
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("x", _vp), ("gamma", _vp), ("beta", _vp), ("out_hi", _vp), ("out_lo", _vp), ("out_f32", _vp),
-                ("M", _i), ("C", _i), ("eps", _f), ("out_layout", _i)]
+                ("M", _i), ("C", _i), ("eps", _f), ("out_layout", _i), ("out_f16", _i)]
 
 
 class AttentionArgs(C.Structure):
     _fields_ = [("qkv_hi", _vp), ("qkv_lo", _vp), ("out_hi", _vp), ("out_lo", _vp), ("B", _i), ("N", _i), ("H", _i),
-                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i), ("out_layout", _i), ("v_format", _i)]
+                ("ld_qkv", _i), ("ld_out", _i), ("scale", _f), ("precision", _i), ("out_layout", _i), ("v_format", _i), ("out_f16", _i)]
 
 
 class ClsRowsArgs(C.Structure):

@@ -61,12 +61,16 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
     if splitk > 1:
         bn = 128 if N >= 1024 else 64
         return f"128, {bn}, 64, 3, 1, splitk" if precision == PREC_BF16X3 else f"128, {bn}, 64, 1, 2, splitk"
-    if precision == PREC_BF16X3 and K % 32 == 0 and K >= 64 and not (N <= 256 and K >= 2048) and os.environ.get("MVP_GEMM_PP", "") != "0":
+    if precision in (PREC_BF16X3, lib.PREC_F16X2) and K % 32 == 0 and K >= 64 and not (N <= 256 and K >= 2048) and os.environ.get("MVP_GEMM_PP", "") != "0":
         t256 = ((M + 255) // 256) * ((N + 255) // 256)  # pp_takes() of csrc/gemm.hip: the large-M ping-pong kernel
         rounds = (t256 + 255) // 256
         if os.environ.get("MVP_GEMM_PP") == "1" or (t256 >= 96 if tile_policy == 1 else (t256 >= 128 if K >= 2048 else t256 >= 200 and (t256 * 5 >= rounds * 1024 or t256 >= 1024))):
             return "pp 256, 256, 32, 3"
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if precision == lib.PREC_F16X2:  # the reduced rule of csrc/gemm.hip for the two-product mode
+        if N >= 1024:
+            return "128, 128, 64, 2, 1"
+        return "64, 64, 64, 2, 1" if ((M + 63) // 64) * ((N + 63) // 64) <= 1280 else "128, 64, 64, 2, 1"
     if precision == PREC_BF16X3:
         if N <= 256 and K >= 2048:
             return "128, 64, 64, 3, 1" if M >= 8192 else "64, 64, 64, 3, 2"
@@ -105,6 +109,21 @@ def split_bf16(src: torch.Tensor, precision: int = PREC_BF16X3) -> Pair:
     a = lib.SplitArgs(lib.ptr(src), lib.ptr(hi), lib.ptr(lo), src.numel())
     lib.call("mvp_split_bf16", a)
     return hi, lo
+
+
+def f16x2_weight(w: torch.Tensor) -> Pair:
+    """The weight operand of a PREC_F16X2 GEMM: (fp16(w) — its bits in a bf16-typed array, like every pair half of this library —,
+    bf16(w)): two roundings of the same value, the partners of the activation's fp16 hi and bf16 lo halves."""
+    w = w.detach().float().contiguous()
+    return w.half().view(torch.bfloat16), w.bfloat16()
+
+
+def split_f16_bf16(src: torch.Tensor) -> Pair:
+    """fp32 -> the activation pair of a PREC_F16X2 GEMM: hi = fp16(x) (bits in a bf16-typed array), lo = bf16(x - hi).  (torch ops: tests
+    and one-off conversions; the kernels write this form themselves.)"""
+    x = src.float()
+    hi = x.half()
+    return hi.view(torch.bfloat16).contiguous(), (x - hi.float()).bfloat16().contiguous()
 
 
 def interleave_pair(pair: Pair) -> Optional[torch.Tensor]:
@@ -212,6 +231,8 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
     if f16_col0:
         args.out_f16_col0 = int(f16_col0)
         splitk, streamk = 1, False
+    if precision == lib.PREC_F16X2:  # two products per contraction: plain linear GEMMs, no split-K / stream-K (mvp_hip.h)
+        splitk, streamk = 1, False
     if out_mask is not None:
         args.out_mask, args.ldm = lib.ptr(out_mask), ldm or N
     if residual_pair is not None:
@@ -246,18 +267,20 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,
-              out_f32: Optional[torch.Tensor] = None) -> None:
+              out_f32: Optional[torch.Tensor] = None, out_f16: bool = False) -> None:
+    """``out_f16``: the pair is written as hi = fp16, lo = bf16 (the activation operand of a PREC_F16X2 GEMM)."""
     ilv = isinstance(out, IlvPair)
     if ilv:
         out = (out.t, None)
     a = lib.LayerNormArgs(lib.ptr(x), lib.ptr(gamma), lib.ptr(beta), lib.ptr(out[0]), lib.ptr(out[1]), lib.ptr(out_f32), M, Cdim, eps,
-                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE)
+                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE, 1 if out_f16 else 0)
     # algorithmic HBM bytes: the fp32 row read once + the bf16 pair (or single bf16) written once
     nb = M * Cdim * (4 + 2 * (2 if (ilv or out[1] is not None) else 1) + (4 if out_f32 is not None else 0))
     _traced("hbm", "layernorm_kernel", 0, float(nb), lambda: lib.call("mvp_layernorm_fwd", a))
 
 
-def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None, v_f16: bool = False) -> None:
+def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None, v_f16: bool = False,
+              out_f16: bool = False) -> None:
     """``v_f16``: the V third of ``qkv`` holds hi = fp16, lo = bf16 (``gemm(..., f16_col0=2 * H * 64)``); the probabilities are then held
     as one fp16 value (mvp_attention_args.v_format = MVP_ATT_V_F16; bf16x3 only)."""
     ilv = isinstance(out, IlvPair)
@@ -265,7 +288,7 @@ def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precis
         out, ld_out = (out.t, None), (ld_out if ld_out is not None else 2 * H * 64)
     a = lib.AttentionArgs(lib.ptr(qkv[0]), lib.ptr(qkv[1]), lib.ptr(out[0]), lib.ptr(out[1]), B, N, H,
                           ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision,
-                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE, 1 if v_f16 else 0)
+                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE, 1 if v_f16 else 0, 1 if out_f16 else 0)
     if _TRACE is None:
         lib.call("mvp_attention_fwd", a)
         return

@@ -32,6 +32,8 @@ class ResNetEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], *, precision="bf16x3", device="cuda"):
         self.device = torch.device(device)
         self.pr = parse_precision(precision)
+        if self.pr == lib.PREC_F16X2:  # a mode of the ViT blocks' GEMMs: the convolution trunk has no two-product kernels
+            self.pr = lib.PREC_BF16X3
         sd = {k: v.detach().to(self.device) for k, v in state_dict.items() if v.dtype.is_floating_point}
         pr = self.pr
         # stem: [C0, 3, 7, 7] -> GEMM operand [C0, 147 -> 192]

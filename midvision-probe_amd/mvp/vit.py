@@ -26,14 +26,19 @@ from .lib import PREC_BF16, PREC_BF16X3
 
 
 def parse_precision(p) -> int:
-    if p in (PREC_BF16, PREC_BF16X3):
+    """'bf16x3' (default: three bf16 products per contraction, ~1e-5 on the features), 'f16x2' (opt-in: the four GEMMs of every block
+    with two products — fp16 hi + bf16 lo activations against fp16 / bf16 roundings of the frozen weights; everything else as in bf16x3;
+    ~3e-4 on the features), 'bf16' (one product: fails the 1e-3 feature contract)."""
+    if p in (PREC_BF16, PREC_BF16X3, lib.PREC_F16X2):
         return p
     s = str(p).lower()
     if s in ("bf16", "fast"):
         return PREC_BF16
     if s in ("bf16x3", "x3", "exact", "fp32"):
         return PREC_BF16X3
-    raise ValueError(f"unknown precision {p!r} (use 'bf16' or 'bf16x3')")
+    if s in ("f16x2", "fp16x2", "x2"):
+        return lib.PREC_F16X2
+    raise ValueError(f"unknown precision {p!r} (use 'bf16x3', 'f16x2' or 'bf16')")
 
 
 class TapOutputs(list):
@@ -117,6 +122,10 @@ class ViTEngine:
                  precision="bf16x3", device="cuda", pos_embed_mode: str = "dino", qkv_fused: bool = True):
         self.device = torch.device(device)
         self.precision = parse_precision(precision)
+        # 'f16x2': a bf16x3 engine (buffers, patch embedding, attention, taps) whose four block GEMMs run two products (lib.PREC_F16X2)
+        self.f16x2 = self.precision == lib.PREC_F16X2
+        if self.f16x2:
+            self.precision = PREC_BF16X3
         self.heads, self.patch, self.ln_eps = heads, patch, ln_eps
         self.att_v_f16 = self.precision == lib.PREC_BF16X3 and os.environ.get("MVP_ATT_V", "f16") != "pair"
         self.pos_embed_mode = pos_embed_mode
@@ -143,6 +152,9 @@ class ViTEngine:
                 fc1_w=ops.split_bf16(sd[p + "mlp.fc1.weight"], self.precision), fc1_b=sd[p + "mlp.fc1.bias"],
                 fc2_w=ops.split_bf16(sd[p + "mlp.fc2.weight"], self.precision), fc2_b=sd[p + "mlp.fc2.bias"],
             )
+            if self.f16x2:  # the weight operands of the two-product GEMMs: (fp16(w), bf16(w))
+                for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w"):
+                    blk[n] = ops.f16x2_weight(sd[p + {"qkv_w": "attn.qkv.weight", "proj_w": "attn.proj.weight", "fc1_w": "mlp.fc1.weight", "fc2_w": "mlp.fc2.weight"}[n]])
             if self.precision == PREC_BF16X3:  # hi|lo-interleaved copies of the frozen weights for the large-M GEMM kernel (mvp.ops.interleave_pair)
                 for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w"):
                     blk[n + "_ilv"] = ops.interleave_pair(blk[n])
@@ -264,18 +276,22 @@ class ViTEngine:
 
     def run_block(self, i: int, ws: dict, B: int, N: int) -> None:
         blk, C, M, pr = self.blocks[i], self.C, B * N, self.precision
+        f2 = self.f16x2
+        gp = lib.PREC_F16X2 if f2 else pr  # precision of the four block GEMMs
         x = ws["x"]
-        ops.layernorm(x, blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps)
+        ops.layernorm(x, blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps, out_f16=f2)
         # bf16x3: the V third of qkv leaves the GEMM as hi = fp16, lo = bf16, and the attention kernel holds its probabilities as one
         # fp16 value (csrc/attention.hip, VF16; MVP_ATT_V=pair brings back the bf16-pair probabilities of rounds 1-3)
         vf16 = self.att_v_f16
-        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=pr, w_ilv=blk.get("qkv_w_ilv"),
+        # (f16x2: Q and K stay bf16 pairs — Q.K^T keeps its three products —, the attention output and fc1's output leave as fp16 hi + bf16 lo)
+        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=gp, w_ilv=blk.get("qkv_w_ilv"),
                  f16_col0=2 * C if vf16 else 0)
-        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16)
-        ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=pr, w_ilv=blk.get("proj_w_ilv"))
-        ops.layernorm(x, blk["n2w"], blk["n2b"], ws["xn"], M, C, self.ln_eps)
-        ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=pr, w_ilv=blk.get("fc1_w_ilv"))
-        ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=pr, w_ilv=blk.get("fc2_w_ilv"))
+        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16, out_f16=f2)
+        ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=gp, w_ilv=blk.get("proj_w_ilv"))
+        ops.layernorm(x, blk["n2w"], blk["n2b"], ws["xn"], M, C, self.ln_eps, out_f16=f2)
+        ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=gp, w_ilv=blk.get("fc1_w_ilv"),
+                 f16_col0=-1 if f2 else 0)
+        ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=gp, w_ilv=blk.get("fc2_w_ilv"))
 
     def forward_taps(self, images: torch.Tensor, layers: Sequence[int], *, bn: Optional[Sequence[dict]] = None,
                      bn_mode: int = 0, pack: bool = True, tap_input_of_block: bool = False, want_cls: bool = False, groups: int = 1):

@@ -136,7 +136,7 @@ def main():
     print("CHECK", "PASS" if ok else "FAIL", flush=True)
     if "--build-only" in sys.argv:
         return 0
-    if "--check-only" in sys.argv or not ok:
+    if "--check-only" in sys.argv or (not ok and "--zeros" not in sys.argv):
         return 0 if ok else 1
 
     if "--stamp" in sys.argv:  # in-kernel s_memtime breakdown of the phases (diagnostic build, MVP_PP_STAMP)
@@ -210,6 +210,8 @@ def main():
             l3.mvp_gemm_pp.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
             l3.mvp_gemm_pp.restype = C.c_int
             extra["round3_kernel"] = l3
+    if "--two-products" in sys.argv:  # what a 2-MFMA-per-product precision mode would cost (the third product dropped: wrong results, timing only)
+        extra["two_products"] = build_ablate(4)
     if "--epilogue-ab" in sys.argv:  # the generic epilogue (gemm_epilogue) instead of the wide one, same main loop
         extra["generic_epilogue"] = build_ablate(0, "MVP_PP_WIDE_EPILOGUE", "wide")
     for B in Bs:
@@ -217,6 +219,9 @@ def main():
         for name, n, k, kw in (("qkv", 2304, 768, {}), ("proj", 768, 768, dict(residual=True, pair_out=False, f32_out=True)),
                                ("fc1", 3072, 768, dict(act=1)), ("fc2", 768, 3072, dict(residual=True, pair_out=False, f32_out=True))):
             d = mk(M, n, k, **kw)
+            if "--zeros" in sys.argv:  # all-zero operands: the same instruction stream at a fraction of the switching power (DVFS check)
+                for t in (d["a"][0], d["a"][1], d["w"][0], d["w"][1], d["ai"], d["wi"]):
+                    t.zero_()
             out = ops.empty_pair((M, n), 3, dev) if d["pair_out"] else None
             o32 = torch.empty(M, n, device=dev) if d["f32_out"] else None
             res = {}
