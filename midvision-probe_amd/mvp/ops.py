@@ -65,7 +65,7 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
         t256 = ((M + 255) // 256) * ((N + 255) // 256)  # pp_takes() of csrc/gemm.hip: the large-M ping-pong kernel
         rounds = (t256 + 255) // 256
         if os.environ.get("MVP_GEMM_PP") == "1" or (t256 >= 96 if tile_policy == 1 else (t256 >= 128 if K >= 2048 else t256 >= 200 and (t256 * 5 >= rounds * 1024 or t256 >= 1024))):
-            return "pp 256, 256, 32, 3"
+            return f"pp 256, 256, 32, {2 if precision == lib.PREC_F16X2 else 3}"
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     if precision == lib.PREC_F16X2:  # the reduced rule of csrc/gemm.hip for the two-product mode
         if N >= 1024:
@@ -252,7 +252,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
         args.splitk, args.splitk_ws, args.splitk_ws_bytes = S, lib.ptr(ws), ws.numel()
     tile = gemm_tile(M, N, K, precision, S, args.tile_policy) if (w_ilv is not None or _TRACE is not None) and not a_ilv else ""
     if a_ilv:
-        tile = "pp 256, 256, 32, 3"
+        tile = f"pp 256, 256, 32, {2 if precision == lib.PREC_F16X2 else 3}"
     if w_ilv is not None and plain and not use_sk and S <= 1 and tile.startswith("pp ") and ldw is None:
         args.w_hi, args.w_lo, args.ldw = lib.ptr(w_ilv), None, 2 * K
         args.pair_layout |= lib.PAIR_W_ILV32
