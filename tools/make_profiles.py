@@ -43,6 +43,6 @@ for k in f:
         continue
     fb, wb = 2.0 * f[k] * 1024.0, w.get(k, 0.0) * 1024.0
     traffic[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb), "dispatches": nf[k]}
-json.dump({"workload": "bench.py default (B=16, 224x224, bf16x3, linear probe)", "correction": "FETCH_SIZE[KiB] x 1024 x 2 + WRITE_SIZE[KiB] x 1024",
+json.dump({"workload": "bench.py default (B=16, 224x224, linear probe; precision = the bench default of that round: bf16x3 through round 3, f16x2 from round 4)", "correction": "FETCH_SIZE[KiB] x 1024 x 2 + WRITE_SIZE[KiB] x 1024",
            "per_launch": traffic}, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print("wrote", sorted(os.listdir(out)))

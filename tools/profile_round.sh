@@ -4,7 +4,7 @@
 # Counters are collected in their own passes with --kernel-trace only (never with sys/hip/hsa tracing), one group per pass
 # (MI355X_MICROARCH.md "rocprofv3 PMC slots": SQ 8 slots, TCC 4; FETCH_SIZE and WRITE_SIZE do not fit one pass).
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 # the default bench command (what the driver runs), without its CPU legs and without the nested PMC children
