@@ -148,6 +148,9 @@ def parse_args():
                          "(tests/test_gpu_kernels.py::test_vit_base_*: the contract is 1e-3); bf16x3 (the library's default): three products, 1.5e-5 ... 2.3e-5, "
                          "timed in the same run and reported as `precision_bf16x3`; bf16: one product, fails the contract (4-6e-3)")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra bf16x3 leg of an f16x2 run")
+    ap.add_argument("--probe-precision", default="bf16x3", choices=["bf16x3", "bf16"],
+                    help="arithmetic of the TRAINED probe's GEMMs / convolutions (fp32 master weights and AdamW either way).  bf16x3 = what the parity tests hold to the "
+                         "reference; bf16 = one product, i.e. ordinary mixed-precision training of the probe on exact frozen features (secondary lines only)")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: batches start in host memory and go through mvp.prefetch.DevicePrefetcher (not the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-oracle steps (~1.8 s each at B=16 on 16 cores: ~11 s bounded sample)")
@@ -256,7 +259,7 @@ def main():
 
         # the counters are collected on the SAME pipeline configuration the timed run uses (grouped forwards, same kernel instantiations);
         # the profiler serialises the kernels, so every launch is alone on the chip
-        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe, "--tiles", args.tiles]
+        wl = ["--batch", str(args.batch), "--image-size", args.image_size, "--precision", args.precision, "--probe", args.probe, "--probe-precision", args.probe_precision, "--tiles", args.tiles]
         if args.inflight is not None:
             wl += ["--inflight", str(args.inflight)]
         if args.group is not None:
@@ -298,10 +301,10 @@ def main():
         torch.manual_seed(0)
         if args.probe == "linear":
             pr = DepthHead(feat_dim=model.feat_dim, head_type="linear", kernel_size=1, prediction_type=args.prediction,
-                           min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+                           min_depth=0.001, max_depth=10, precision=args.probe_precision).to(dev)
         else:
             pr = DepthHead(feat_dim=model.feat_dim, head_type="dpt", kernel_size=3, prediction_type=args.prediction, hidden_dim=512,
-                           min_depth=0.001, max_depth=10, precision=args.precision).to(dev)
+                           min_depth=0.001, max_depth=10, precision=args.probe_precision).to(dev)
         # N > 1: rank 0's probe is broadcast at construction (DDP semantics); the flat-gradient all-reduce of step t runs
         # under the frozen forward of step t+1 and its AdamW update lands right before the probe forward
         op = FlatAdamW([{"params": pr.parameters(), "lr": 5e-4}], overlap_comm=world > 1)
@@ -476,16 +479,23 @@ def main():
         res = {}
         for label, pinned in (("pageable", False), ("pinned", True)):
             src = [{k: (v.pin_memory() if pinned else v) for k, v in b.items()} for b in hb]
-            seq = [src[i % n_distinct] for i in range(args.warmup + args.steps)]
             from mvp.pipeline import pipelined_features
 
-            # as mvp.train.train() does: prefetcher (side-stream H2D into recycled device buffers) -> forwards in flight -> probe steps
-            t1 = None
-            for i, (b, feats) in enumerate(pipelined_features(model, DevicePrefetcher(seq, dev, depth=2), depth=pipe.depth)):
-                if i == args.warmup:
-                    barrier()
-                    t1 = time.perf_counter()
-                loss_acc += train_depth_step(model, probe, opt, sched, loss_fn, None, b["depth"], feats=feats)
+            # as mvp.train.train() does: prefetcher (side-stream H2D into recycled device buffers) -> forwards in flight -> probe steps.
+            # Two separate passes, each from an EMPTY pipeline to an empty one (the rule of the headline's timed region): a warm-up pass,
+            # then the timed pass — were the clock started in the middle of one pass, the span forwards already submitted for the next
+            # ~7 batches would fall outside it (round 3's figures of this leg were taken that way, with single-batch forwards: a smaller error).
+            def h2d_pass(n):
+                seq = [src[i % n_distinct] for i in range(n)]
+                acc = torch.zeros((), device=dev)
+                for b, feats in pipelined_features(model, DevicePrefetcher(seq, dev, depth=2), depth=pipe.depth):
+                    acc += train_depth_step(model, probe, opt, sched, loss_fn, None, b["depth"], feats=feats)
+                return acc
+
+            h2d_pass(max(args.warmup, 8))
+            barrier()
+            t1 = time.perf_counter()
+            loss_acc += h2d_pass(args.steps)
             barrier()
             res[label] = round(world * B * args.steps / (time.perf_counter() - t1), 1)
         sync_t = time.perf_counter()
@@ -678,7 +688,7 @@ def main():
             "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",
             "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(" + ("linear,k=1" if args.probe == "linear" else "dpt,k=3,hidden512") + f",{args.prediction}) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",
                        "per_gpu_batch": B, "global_batch": B * world, "tokens_per_image": N, "parallelism": f"dp{world}",
-                       "precision": args.precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
+                       "precision": args.precision, "probe_precision": args.probe_precision, "alg_gflop_per_image": round(f_img / 1e9, 2)},
             "mean_loss": round(last_loss, 5),
             "pipeline": pipeline_info,
             "sustained": sustained,

@@ -204,7 +204,7 @@ MAX_SPAN_PATTERNS = 16  # (slot, carry) patterns whose graphs are captured up fr
 def default_span(model, images: torch.Tensor, depth: int, group: int) -> int:
     """IMAGES per forward when forwards may end in the middle of a batch (0: whole batches only).  MVP_PIPELINE_SPAN wins when set.
     As many images as keep the narrowest GEMM of a block (N = C columns: ceil(C / 256) column tiles of the 256x256 kernel) within
-    one round of 256 CUs, rounded down to a multiple of B / 8 (few carry patterns); 0 when that is a whole number of batches anyway
+    one round of the device's CUs (256 on MI355X; mvp_info().cu_count), rounded down to a multiple of B / 8 (few carry patterns); 0 when that is a whole number of batches anyway
     (then ``group`` covers it), less than one batch, the pipeline is not the two-slot one, or a single batch already fills a forward
     (``group`` 1, e.g. B = 16 at 480x640: 18 images per forward on one stream measured 1293 img/s against 1349 for single batches on
     three streams, whose chains fill each other's partial rounds; at 224^2, B = 16 / 64: 8967 / 9203 against 8514 / 8191)."""
@@ -226,8 +226,19 @@ def default_span(model, images: torch.Tensor, depth: int, group: int) -> int:
         H, W = images.shape[-2], images.shape[-1]
         rows = rows_per_image(H, W, P)
         unit = max(1, B // 8)
-        T = min(((256 // (-(-C // 256))) * 256) // rows, MAX_GROUP * B) // unit * unit
+        T = min(((_cu_count() // (-(-C // 256))) * 256) // rows, MAX_GROUP * B) // unit * unit
     return T if (T > B and T % B) else 0
+
+
+def _cu_count() -> int:
+    """Compute units of the current device (one 256x256 tile of the large-M GEMM per CU and round); 256 when the library cannot say."""
+    try:
+        from . import lib
+
+        n = int(lib.info().cu_count)
+        return n if n > 0 else 256
+    except Exception:
+        return 256
 
 
 def span_patterns(T: int, B: int):

@@ -207,6 +207,53 @@ def test_dpt_probe_fwd_bwd_vs_oracle(dev, kind):
     print(f"\n[dpt {kind}] worst param-grad rel-L2 = {worst:.2e}")
 
 
+def test_dpt_probe_trained_in_bf16_tracks_the_three_product_probe_within_the_depth_rmse_tolerance(dev):
+    """`precision="bf16"` for the TRAINED probe (`bench.py --probe-precision bf16`: ordinary mixed-precision training — one bf16 MFMA product per
+    convolution, fp32 accumulation, fp32 master weights and AdamW — on exact frozen features) is a secondary, opt-in mode; the parity tests above
+    hold the default three-product probe to the reference.  What BASELINE.json's north star asks of the depth output is 1e-2 on depth RMSE: from one
+    initialisation, on the same features and targets, 12 training steps in either arithmetic end with depth RMSEs within 1e-2 (relative) of each
+    other, step by step, and with loss trajectories within 1e-2.  (Reference: train_depth.py:99-144, probes.py:215-399.)"""
+    from evals.models.probes import DepthHead
+    from evals.utils.losses import DepthLoss
+    from mvp import functional as MF
+    from mvp.optim import FlatAdamW
+    from oracle import probes as oprobes
+
+    C, Hd, B, h, w = 128, 128, 4, 5, 6
+    g = torch.Generator().manual_seed(123)
+    batches = []
+    for _ in range(3):
+        feats = [torch.randn(B, C, h, w, generator=g).to(dev) for _ in range(4)]
+        tgt = (torch.rand(B, 1, 16 * h, 16 * w, generator=g) * 9.9 + 0.05)
+        tgt[torch.rand(tgt.shape, generator=g) < 0.1] = 0.0
+        batches.append((feats, tgt.to(dev)))
+    sd = oprobes.make_dpt_weights([C] * 4, 256, hidden=Hd, k=3, seed=5)
+    out = {}
+    for prec in ("bf16x3", "bf16"):
+        probe = DepthHead(feat_dim=[C] * 4, head_type="dpt", prediction_type="bindepth", hidden_dim=Hd, kernel_size=3, precision=prec)
+        probe.load_state_dict(sd, strict=True)
+        probe = probe.to(dev)
+        opt = FlatAdamW([{"params": probe.parameters(), "lr": 5e-4}])
+        loss_fn = DepthLoss()
+        losses, rmses = [], []
+        for step in range(12):
+            feats, tgt = batches[step % 3]
+            opt.zero_grad()
+            pred = MF.interpolate(probe(feats), size=tgt.shape[-2:], mode="bilinear")
+            loss = loss_fn(pred, tgt.clone())
+            loss.backward()
+            opt.step()
+            valid = tgt > 0
+            rmses.append(float(((pred.detach() - tgt)[valid] ** 2).mean().sqrt()))
+            losses.append(float(loss))
+        out[prec] = (np.array(losses), np.array(rmses))
+    torch.cuda.synchronize()
+    (la, ra), (lb, rb) = out["bf16x3"], out["bf16"]
+    print(f"\n[dpt probe bf16 vs bf16x3] max rel diff: loss {np.abs(lb / la - 1).max():.2e}, depth RMSE {np.abs(rb / ra - 1).max():.2e}; RMSE {ra[0]:.4f} -> {ra[-1]:.4f}")
+    assert np.isfinite(lb).all() and ra[-1] < ra[0]  # it trains
+    assert np.abs(rb / ra - 1).max() < 1e-2 and np.abs(lb / la - 1).max() < 1e-2
+
+
 @pytest.mark.parametrize("pt", ["bindepth", "sigdepth"])
 def test_linear_probe_k3_vs_oracle(dev, pt):
     """probes.py:417-432 with kernel_size=3 (no conv/resample commutation: explicit bilinear x4 + 3x3 conv)."""
