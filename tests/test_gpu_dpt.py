@@ -250,7 +250,7 @@ def test_dpt_probe_trained_in_bf16_tracks_the_three_product_probe_within_the_dep
     torch.cuda.synchronize()
     (la, ra), (lb, rb) = out["bf16x3"], out["bf16"]
     print(f"\n[dpt probe bf16 vs bf16x3] max rel diff: loss {np.abs(lb / la - 1).max():.2e}, depth RMSE {np.abs(rb / ra - 1).max():.2e}; RMSE {ra[0]:.4f} -> {ra[-1]:.4f}")
-    assert np.isfinite(lb).all() and ra[-1] < ra[0]  # it trains
+    assert np.isfinite(lb).all() and la[-3:].mean() < la[:3].mean() and lb[-3:].mean() < lb[:3].mean()  # both train (the scale-invariant loss falls)
     assert np.abs(rb / ra - 1).max() < 1e-2 and np.abs(lb / la - 1).max() < 1e-2
 
 
