@@ -172,6 +172,7 @@ typedef struct {
 #define MVP_TILES_ALONE 0
 #define MVP_TILES_SHARED 1
 #define MVP_TILES_NO_PP 2 /* flag, or-ed in: never dispatch to the large-M kernel mvp_gemm_pp (A/B measurements, tests of the tile kernels) */
+#define MVP_TILES_NO_UNI 4 /* flag, or-ed in: keep the row-guarded epilogue where the universal branch-free one (gemm_epilogue_uni) would serve (A/B, bit-identity tests) */
 #define MVP_GEMM_STREAMK (-1)
 #define MVP_PAIR_SEPARATE 0
 #define MVP_PAIR_A_ILV32 1

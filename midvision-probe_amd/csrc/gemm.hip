@@ -363,6 +363,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
     if (tid == 0) __hip_atomic_store(ctr + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
   }
 
+  if constexpr ((WN == 64 || WN == 32) && NT == WN / 16) {
+    // the universal branch-free epilogue wherever its alignment / size conditions hold (same bits as the row-guarded one)
+    if (gemm_epilogue_uni_ok(p) && !(p.tile_policy & MVP_TILES_NO_UNI)) {
+      gemm_epilogue_uni<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0, [] {});
+      return;
+    }
+  }
   gemm_epilogue<NT, MT, WN, EXT>(p, acc, smem, wave, lane, m0, n0, wm0, wn0);
 }
 
@@ -446,13 +453,21 @@ static bool pp_takes(const mvp_gemm_args* a) {
     // the im2col staging, its fused masks / residuals through the generic epilogue; from two full rounds of 256x256 tiles on
     if (a->pair_layout != MVP_PAIR_SEPARATE || (a->tile_policy & MVP_TILES_NO_PP) || (a->cC & 31) || a->K < 1024 || a->residual_hi) return false;
     if (env >= 0) return env != 0;
+    if ((long)((a->N + 255) / 256) * 256 * 7 > (long)a->N * 8) return false;  // (narrow outputs: see below)
     return (long)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 512;
   }
-  if (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) return false;
+  if (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) {
+    // masked / pair-residual epilogues (the ResNet-50 trunk's residual-adding 1x1 layers: M = 230 400 ... 14 400 rows, K = 64 ... 512 — all
+    // epilogue): the large-M kernel when its universal branch-free epilogue serves the form, by the short-K rule below
+    if (!gemm_epilogue_uni_ok(*a) || (a->tile_policy & (MVP_TILES_NO_UNI | MVP_TILES_NO_PP)) || a->precision != MVP_PREC_BF16X3 || a->pair_layout != MVP_PAIR_SEPARATE) return false;
+  }
   if (a->pair_layout != MVP_PAIR_SEPARATE) return true;  // only that kernel reads the interleaved layout
   if (a->tile_policy & MVP_TILES_NO_PP) return false;
   if (env >= 0) return env != 0;
   if (a->N <= 256 && a->K >= 2048) return false;  // the probe head: few tiles, split-K
+  // a 256-column tile on a narrow output issues MFMAs for columns that do not exist (N = 64: 4x; the ResNet-50 trunk's layer1 / layer2
+  // bottlenecks ran 125 us on it for 60 us of operand streaming): at most 1/8 of the columns of the tile grid may be padding
+  if ((long)((a->N + 255) / 256) * 256 * 7 > (long)a->N * 8) return false;
   const long t = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   if (a->tile_policy & MVP_TILES_SHARED) return t >= 96;  // other chains fill what a partly filled round leaves idle
   if (a->K >= 2048) return t >= 128;

@@ -388,6 +388,186 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
   }
 }
 
+// The universal branch-free epilogue (round 4): gemm_epilogue()'s arithmetic — bias, GELU / ReLU before or after the residuals, the
+// ReLU gate (relu_mask, both mask modes), an fp32 residual and / or a residual given as a bf16 pair, the byte mask of a ReLU's output,
+// fp32 and / or pair output (bf16 or fp16-hi form), row remaps — in gemm_epilogue_wide()'s shape: a lane owns 8 consecutive columns of
+// one row, every global access is a buffer instruction (out-of-range sentinel for rows >= M / columns >= N, zero-sized resources for
+// absent operands: a load of an absent residual returns zeros and adding them changes nothing), the next 16-row unit's loads are issued
+// ahead of the current unit's stores, the only branches are wave-uniform ones around vector arithmetic.  For wave tiles of 64 or 32
+// columns: every tile kernel of gemm.hip (the ResNet-50 trunk's 1x1 / 3x3 convolutions, whose residual-adding 1x1 layers at
+// K = 64 ... 512 are all epilogue — tools/resnet_bench.py: 35 % of the forward at 0.4 of the HBM rate with the row-guarded epilogue and its
+// vmcnt(0) per row group —, the DPT probe's convolutions, the serial loop's qkv / fc1) and the EXT instantiations of the large-M kernel.
+// Not covered (gemm_epilogue() stays): residual2, N % 8 != 0, unaligned or >= 2 GiB arrays (gemm_epilogue_uni_ok()).
+// The results are gemm_epilogue()'s bit for bit (same operations in the same order per element).
+// EXT = false compiles the gate / mask / pair-residual / post-residual-ReLU parts out, as in gemm_epilogue().
+__host__ __device__ __forceinline__ bool gemm_epilogue_uni_ok(const mvp_gemm_args& p) {
+  if ((p.N & 7) || p.residual2) return false;
+  if (p.act != MVP_ACT_NONE && p.act != MVP_ACT_GELU && p.act != MVP_ACT_RELU) return false;
+  const int64_t lim = 0x7fffff00ll;
+  const int64_t rows = p.row_group > 0 ? ((int64_t)(p.M - 1) / p.row_group) * p.row_group_stride + p.row_group_off + p.row_group : p.M;
+  const int64_t rrows = p.res_row_mod > 0 ? (int64_t)p.res_row_mod : rows;
+  if (p.bias && (((size_t)p.bias & 15) || (int64_t)p.N * 4 > lim)) return false;
+  if (p.out_f32 && ((p.ldo & 3) || ((size_t)p.out_f32 & 15) || rows * p.ldo * 4 > lim)) return false;
+  if (p.out_hi && ((p.ldob & 7) || ((size_t)p.out_hi & 15) || (p.out_lo && ((size_t)p.out_lo & 15)) || rows * p.ldob * 2 + 64 > lim)) return false;
+  if (p.residual && ((p.ldr & 3) || ((size_t)p.residual & 15) || rrows * p.ldr * 4 > lim)) return false;
+  if (p.residual_hi && ((p.ldr & 7) || ((size_t)p.residual_hi & 15) || (p.residual_lo && ((size_t)p.residual_lo & 15)) || rrows * p.ldr * 2 > lim)) return false;
+  if ((p.relu_mask || p.out_mask) && ((p.ldm & 7) || rows * p.ldm > lim)) return false;
+  if (p.relu_mask && (((size_t)p.relu_mask & 7) || (p.mask_mode != 1 && p.mask_mode != 2))) return false;
+  if (p.out_mask && ((size_t)p.out_mask & 7)) return false;
+  return true;
+}
+
+template <int NT, int MT, int WN, bool EXT, class ARGS = mvp_gemm_args, class HOOK>
+__device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
+                                                  const int m0, const int n0, const int wm0, const int wn0, HOOK&& after_first_loads) {
+  static_assert((WN == 64 || WN == 32) && NT == WN / 16, "wave tile 16k x 64 or 16k x 32");
+  constexpr int EPW = WN + 4;                 // padded scratch row, floats
+  constexpr int EP_BYTES = 16 * EPW * 4;      // per wave
+  constexpr int SENT = 0x7fffff00;            // out-of-range byte offset (every resource below has at most that many bytes)
+  constexpr int LPR = WN / 8;                 // lanes per output row (8 columns each): 8 or 4
+  constexpr int RPI = 64 / LPR;               // rows per wave-instruction: 8 or 16
+  constexpr int HIT = 16 / RPI;               // wave-instructions per 16-row unit: 2 or 1
+  const int frow = lane & 15, fq = lane >> 4;
+  float* ep = (float*)(smem + wave * EP_BYTES);
+  const int er = lane / LPR, ec = (lane % LPR) * 8;
+  const int ncol = n0 + wn0 + ec;
+  const bool col_ok = ncol < p.N;  // (N % 8 == 0: the 8 columns are all in or all out)
+  auto rsrc = [](const void* ptr) { return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, ptr ? SENT : 0, 0x00020000); };  // null: every access out of range
+  const uint8_t* x_gate = EXT ? p.relu_mask : nullptr;
+  uint8_t* x_omask = EXT ? p.out_mask : nullptr;
+  const mvp_bf16* x_rhi = EXT ? p.residual_hi : nullptr;
+  const mvp_bf16* x_rlo = EXT ? p.residual_lo : nullptr;
+  const bool act_after = EXT && p.act_after_res != 0;
+  const int mask_mode = EXT ? p.mask_mode : 0;
+  const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;
+  const __amdgpu_buffer_rsrc_t r_bias = rsrc(p.bias), r_res = rsrc(p.residual), r_rhi = rsrc(x_rhi), r_rlo = rsrc(x_rlo), r_gate = rsrc(x_gate);
+  const __amdgpu_buffer_rsrc_t r_o32 = rsrc(p.out_f32), r_ohi = rsrc(p.out_hi), r_omask = rsrc(x_omask);
+  const __amdgpu_buffer_rsrc_t r_olo = rsrc(oilv ? (const void*)p.out_hi : (const void*)p.out_lo);  // interleaved: the lo half sits 64 bytes behind the hi half
+  const int lo_soff = oilv ? 64 : 0;
+  const bool has_pair = p.out_hi != nullptr;
+  const bool f16_cols = has_pair && p.out_f16_col0 != 0 && (n0 + wn0) >= p.out_f16_col0;  // (wave-uniform: out_f16_col0 % 64 == 0 or -1)
+  const int ob = col_ok ? ncol * 4 : SENT;
+  const u32x4_t bias_a = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 0, 0), bias_b = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 16, 0);
+  const int pcol = oilv ? ilv32_col(ncol) : ncol;
+  struct row_off { int o32, opair, res, rpair, mask; };
+  auto offsets = [&](int m) {
+    row_off o;
+    const bool ok = (m < p.M) && col_ok;
+    int orow = m;
+    if (p.row_group > 0) {  // (wave-uniform: the patch embedding's output-row remap)
+      const int gidx = m / p.row_group;
+      orow = gidx * p.row_group_stride + p.row_group_off + (m - gidx * p.row_group);
+    }
+    const int rrow = (p.res_row_mod > 0) ? (m % p.res_row_mod) : orow;
+    o.o32 = ok ? (orow * p.ldo + ncol) * 4 : SENT;
+    o.opair = ok ? (orow * p.ldob + pcol) * 2 : SENT;
+    o.res = ok ? (rrow * p.ldr + ncol) * 4 : SENT;
+    o.rpair = ok ? (rrow * p.ldr + ncol) * 2 : SENT;
+    o.mask = ok ? (orow * p.ldm + ncol) : SENT;
+    return o;
+  };
+  u32x4_t rpre[HIT][2], ppre[HIT][2];  // next unit's fp32 residual (8 floats) and pair residual (8 hi, 8 lo bf16)
+  u32x2_t gpre[HIT];                   // next unit's gate bytes
+  row_off ro[HIT], ro_next[HIT];
+  auto load_next = [&](int u) {
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      ro_next[it] = offsets(m0 + wm0 + u * 16 + it * RPI + er);
+      rpre[it][0] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 0, 0);
+      rpre[it][1] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 16, 0);
+      if (EXT) {
+        ppre[it][0] = __builtin_amdgcn_raw_buffer_load_b128(r_rhi, ro_next[it].rpair, 0, 0);
+        ppre[it][1] = __builtin_amdgcn_raw_buffer_load_b128(r_rlo, ro_next[it].rpair, 0, 0);
+        gpre[it] = __builtin_amdgcn_raw_buffer_load_b64(r_gate, ro_next[it].mask, 0, 0);
+      }
+    }
+  };
+  load_next(0);
+  after_first_loads();
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { bias8[e] = u2f(bias_a[e]); bias8[4 + e] = u2f(bias_b[e]); }
+#pragma unroll
+  for (int u = 0; u < MT; ++u) {
+    __builtin_amdgcn_sched_barrier(0);  // (straight-line code: keep the scheduler from pulling later units forward until the registers run out)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *(f32x4_t*)(ep + frow * EPW + i * 16 + fq * 4) = acc[i][u];
+    float v[HIT][8], vp[HIT][8];  // value for the fp32 output / for the pair output (they differ under mask_mode 1)
+    uint32_t mbits[HIT][2];       // the 8 mask bytes of a lane's columns (out_mask)
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      ro[it] = ro_next[it];
+      const int lr = it * RPI + er;
+      const f32x4_t a = *(const f32x4_t*)(ep + lr * EPW + ec), b = *(const f32x4_t*)(ep + lr * EPW + ec + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[it][e] = a[e] + bias8[e]; v[it][4 + e] = b[e] + bias8[4 + e]; }
+      if (p.act == MVP_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] = gelu_erf(v[it][e]);
+      } else if (p.act == MVP_ACT_RELU && !act_after) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
+      }
+      mbits[it][0] = mbits[it][1] = 0u;
+      if (EXT && x_omask && !act_after) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mbits[it][e >> 2] |= (v[it][e] > 0.f ? 1u : 0u) << (8 * (e & 3));
+      }
+      float keep[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) keep[e] = 1.f;
+      if (EXT && x_gate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) keep[e] = ((gpre[it][e >> 2] >> (8 * (e & 3))) & 0xffu) ? 1.f : 0.f;
+        if (mask_mode == 2) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[it][e] *= keep[e];
+        }
+      }
+      if (p.residual) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[it][e] += u2f(rpre[it][0][e]); v[it][4 + e] += u2f(rpre[it][1][e]); }
+      }
+      if (EXT && x_rhi) {  // residual kept only as a bf16 pair (ResNet identities): v += hi + lo, the sum formed first as in gemm_epilogue()
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t hw = ppre[it][0][e >> 1], lw = ppre[it][1][e >> 1];  // (an absent lo array reads as zeros)
+          v[it][e] += u2f((e & 1) ? (hw & 0xffff0000u) : (hw << 16)) + u2f((e & 1) ? (lw & 0xffff0000u) : (lw << 16));
+        }
+      }
+      if (p.act == MVP_ACT_RELU && act_after) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[it][e] = fmaxf(v[it][e], 0.f);
+        if (x_omask) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) mbits[it][e >> 2] |= (v[it][e] > 0.f ? 1u : 0u) << (8 * (e & 3));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vp[it][e] = (EXT && mask_mode == 1) ? v[it][e] * keep[e] : v[it][e];
+    }
+    if (u + 1 < MT) load_next(u + 1);  // issued BEFORE this unit's stores: its data never waits behind them
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][0]), f2u(v[it][1]), f2u(v[it][2]), f2u(v[it][3])}, r_o32, ro[it].o32, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][4]), f2u(v[it][5]), f2u(v[it][6]), f2u(v[it][7])}, r_o32, ro[it].o32, 16, 0);
+      uint32_t hw[4] = {0u, 0u, 0u, 0u}, lw[4] = {0u, 0u, 0u, 0u};
+      if (has_pair) {
+        if (f16_cols) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16_bf16(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_bf16(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].opair, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].opair, lo_soff, 0);
+      if (EXT) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{mbits[it][0], mbits[it][1]}, r_omask, ro[it].mask, 0, 0);
+    }
+  }
+}
+
 // Which wide-epilogue instantiation serves these arguments (0 = none: the generic epilogue).
 __host__ __device__ __forceinline__ int gemm_epilogue_wide_variant(const mvp_gemm_args& p) {
   {  // the wide epilogues address every array through a buffer resource with 32-bit byte offsets: all of them below 2 GiB

@@ -379,6 +379,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 #define MVP_PP_WIDE_EPILOGUE 1  // 0 (diagnostic builds): always the generic epilogue
 #endif
   const int wide = (!EXT && MVP_PP_WIDE_EPILOGUE) ? gemm_epilogue_wide_variant(p) : 0;  // wave-uniform: kernel arguments only
+  // EXT instantiations (masks, pair residuals, post-residual ReLU): the universal branch-free epilogue where it serves the form
+  const bool uni = EXT && MVP_PP_WIDE_EPILOGUE && gemm_epilogue_uni_ok(p) && !(p.tile_policy & MVP_TILES_NO_UNI);
 
   // ---------------------------------------------------------------- first tile: the cold prologue — HA0(0), HB(0), HA1(0), then what "P2(-1)" would issue
   int bid = blockIdx.x;
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
 
     const int nbid = bid + (int)gridDim.x;
     const bool has_next = nbid < tiles;
-    const bool pre = has_next && wide != 0 && MVP_PP_PREFETCH;
+    const bool pre = has_next && (wide != 0 || uni) && MVP_PP_PREFETCH;
     if (has_next) setup_tile(nbid);
     // Ahead of the epilogue's stores (vmcnt retires in order), behind its first loads: the next tile's first k-step into buffer 0.
     // Issued UNCONDITIONALLY — without a next tile as 8 dead pieces (zero-sized resource) into buffer 1, which nothing uses then: were
@@ -461,6 +463,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
       case 5: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_GELU, false, true, false>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
       case 6: gemm_epilogue_wide<NT, MT, WN, MVP_ACT_NONE, false, true, false, true>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch); break;
       default:
+        if constexpr (EXT) {
+          if (uni) {
+            gemm_epilogue_uni<NT, MT, WN, true>(pe, acc, scratch, wave, lane_e, m0c, n0c, wm0, wn0, prefetch);
+            break;
+          }
+        }
         gemm_epilogue<NT, MT, WN, EXT>(pe, acc, smem, wave, lane_e, m0c, n0c, wm0, wn0);
         // The generic epilogue guards its rows with branches, and hipcc's wait-count pass must assume that a skipped row leaves that
         // row's bias / residual / mask loads pending: without a wait it can SEE here it would protect their destination registers with
@@ -552,8 +560,9 @@ int launch_pp(const mvp_gemm_args* a, hipStream_t s) {
   }();
   if (configured != 0) return MVP_ELAUNCH;
   const int grid = pp_grid(a);
-  // (the gated-input-gradient combination has a wide epilogue of its own in the plain instantiation)
-  const bool ext = (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) && gemm_epilogue_wide_variant(*a) != 6;
+  // The plain instantiation carries the specialised wide epilogues of the ViT blocks (+ the gated input gradient); every other form goes
+  // to the EXT instantiation, whose universal branch-free epilogue serves masks, pair residuals, a ReLU before or after the residual ...
+  const bool ext = gemm_epilogue_wide_variant(*a) == 0;
   if (ext)
     hipLaunchKernelGGL((gemm_pp_kernel<ILVA, ILVW, true, CONV>), dim3(grid), dim3(512), PP_SMEM, s, *a);
   else

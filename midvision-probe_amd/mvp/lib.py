@@ -22,7 +22,7 @@ PREC_F16X2 = 2  # two products per GEMM contraction (fp16 hi + bf16 lo activatio
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BICUBIC = 0, 1, 2
 PAIR_SEPARATE, PAIR_A_ILV32, PAIR_W_ILV32 = 0, 1, 2  # mvp_gemm_args.pair_layout (bit flags)
-TILES_SHARED, TILES_NO_PP = 1, 2
+TILES_SHARED, TILES_NO_PP, TILES_NO_UNI = 1, 2, 4
 
 _vp = C.c_void_p
 _i = C.c_int

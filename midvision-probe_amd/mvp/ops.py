@@ -64,7 +64,8 @@ def gemm_tile(M: int, N: int, K: int = 0, precision: int = PREC_BF16X3, splitk: 
     if precision in (PREC_BF16X3, lib.PREC_F16X2) and K % 32 == 0 and K >= 64 and not (N <= 256 and K >= 2048) and os.environ.get("MVP_GEMM_PP", "") != "0":
         t256 = ((M + 255) // 256) * ((N + 255) // 256)  # pp_takes() of csrc/gemm.hip: the large-M ping-pong kernel
         rounds = (t256 + 255) // 256
-        if os.environ.get("MVP_GEMM_PP") == "1" or (t256 >= 96 if tile_policy == 1 else (t256 >= 128 if K >= 2048 else t256 >= 200 and (t256 * 5 >= rounds * 1024 or t256 >= 1024))):
+        narrow = ((N + 255) // 256) * 256 * 7 > N * 8  # more than 1/8 of the tile grid's columns would be padding
+        if os.environ.get("MVP_GEMM_PP") == "1" or not narrow and (t256 >= 96 if tile_policy == 1 else (t256 >= 128 if K >= 2048 else t256 >= 200 and (t256 * 5 >= rounds * 1024 or t256 >= 1024))):
             return f"pp 256, 256, 32, {2 if precision == lib.PREC_F16X2 else 3}"
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     if precision == lib.PREC_F16X2:  # the reduced rule of csrc/gemm.hip for the two-product mode

@@ -578,6 +578,75 @@ def test_gemm_two_product_mode_vs_fp64_and_across_kernel_families(dev, shape):
                 assert torch.equal(outs[pol][1][0], outs["tile"][1][0]) and torch.equal(outs[pol][1][1], outs["tile"][1][1]), (shape, pol, form)
 
 
+@pytest.mark.parametrize("shape", [(1000, 256, 64), (3001, 1024, 256), (65500, 256, 64), (140000, 512, 128), (70000, 64, 256), (200000, 128, 64)])
+def test_universal_epilogue_bits_equal_the_row_guarded_one(dev, shape):
+    """gemm_epilogue_uni (round 4: branch-free buffer loads / stores, next unit's loads ahead of this unit's stores) against gemm_epilogue
+    (rows guarded by branches) on the forms the ResNet-50 trunk, the DPT probe and the ViT use: ReLU -> pair; pair residual + ReLU after it ->
+    pair + fp32 (ResNet identities, dino_res50.py:83-101); stored-gate backward (mask_mode 2 and 1); ReLU with its byte mask out; fp32
+    residual + GELU.  Same launches with MVP_TILES_NO_UNI switched on and off, on the 128-column tile kernels and on the large-M kernel:
+    every output (fp32, pair halves, mask bytes) bit for bit, ragged last row tile included.  Shapes: 64x64 tiles (no 64-column wave
+    tile: the guarded epilogue either way), 128x128 tiles (universal), the large-M kernel with one tile per workgroup (256 tiles) and with
+    its tile loop (1094 tiles: the next tile's operands are fetched under the universal epilogue)."""
+    import ctypes as C
+
+    from mvp import lib, ops
+
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 7 * N)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    ap, wp = ops.split_bf16(a, 3), ops.split_bf16(w, 3)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    rp = ops.split_bf16(torch.randn(M, N, generator=g).to(dev), 3)
+    gate = (torch.rand(M, N, generator=g) > 0.4).to(torch.uint8).to(dev)
+    so = lib.load()
+    forms = {
+        "relu_pair": dict(act=lib.ACT_RELU, pair=True),
+        "respair_relu_after": dict(act=lib.ACT_RELU, pair=True, f32=True, respair=True, act_after=True),
+        "respair_hi_only": dict(act=lib.ACT_RELU, pair=True, respair="hi", act_after=True),
+        "gate2_f32": dict(f32=True, gate=2),
+        "gate1_both": dict(f32=True, pair=True, gate=1, res=True),
+        "relu_mask_out": dict(act=lib.ACT_RELU, pair=True, f32=True, omask=True),
+        "relu_after_mask_out": dict(act=lib.ACT_RELU, pair=True, omask=True, res=True, act_after=True),
+        "res_gelu_pair": dict(act=lib.ACT_GELU, pair=True, res=True),
+    }
+    for name, f in forms.items():
+        outs = {}
+        for pol_name, pol in (("tile_generic", lib.TILES_NO_PP | lib.TILES_NO_UNI), ("tile_uni", lib.TILES_NO_PP), ("auto_uni", 0)):
+            o32 = torch.full((M, N), float("nan"), device=dev) if f.get("f32") else None
+            op = ops.empty_pair((M, N), 3, dev) if f.get("pair") else None
+            if op is not None:
+                op[0].fill_(float("nan")); op[1].fill_(float("nan"))
+            om = torch.full((M, N), 77, dtype=torch.uint8, device=dev) if f.get("omask") else None
+            args = lib.GemmArgs(lib.ptr(ap[0]), lib.ptr(ap[1]), lib.ptr(wp[0]), lib.ptr(wp[1]), lib.ptr(bias), lib.ptr(res) if f.get("res") else None,
+                                lib.ptr(o32), lib.ptr(op[0]) if op else None, lib.ptr(op[1]) if op else None, M, N, K, K, K, N, N, N,
+                                f.get("act", lib.ACT_NONE), lib.PREC_BF16X3, 0, 0, 0, 0)
+            if f.get("gate"):
+                args.relu_mask, args.mask_mode, args.ldm = lib.ptr(gate), f["gate"], N
+            if om is not None:
+                args.out_mask, args.ldm = lib.ptr(om), N
+            if f.get("respair"):
+                args.residual_hi = lib.ptr(rp[0])
+                args.residual_lo = None if f["respair"] == "hi" else lib.ptr(rp[1])
+            args.act_after_res = int(bool(f.get("act_after")))
+            args.tile_policy = pol
+            lib.check(so.mvp_gemm_bias_act_res(C.byref(args), lib.stream_ptr()), f"{name}/{pol_name}")
+            torch.cuda.synchronize()
+            outs[pol_name] = (o32, op, om)
+        ref = outs["tile_generic"]
+        if ref[0] is not None:
+            assert torch.isfinite(ref[0]).all()
+        for pol_name in ("tile_uni", "auto_uni"):
+            got = outs[pol_name]
+            if ref[0] is not None:
+                assert torch.equal(got[0], ref[0]), (shape, name, pol_name, "f32")
+            if ref[1] is not None:
+                assert torch.equal(got[1][0], ref[1][0]) and torch.equal(got[1][1], ref[1][1]), (shape, name, pol_name, "pair")
+            if ref[2] is not None:
+                assert torch.equal(got[2], ref[2]), (shape, name, pol_name, "mask")
+
+
 @pytest.mark.parametrize("shape", [(18912, 3072, 768), (5000, 768, 3072), (300, 512, 96)])
 def test_gemm_pp_interleaved_layouts_match_separate(dev, shape):
     """mvp_gemm_args.pair_layout / out_pair_layout: the large-M kernel on hi|lo-interleaved A and / or W operands, and writing an
