@@ -533,7 +533,10 @@ extern "C" int mvp_gemm_tn_conv(const mvp_gemm_tn_args* a, void* stream) {
 #ifndef MVP_TN_KT
 #define MVP_TN_KT 64
 #endif
-    return launch_tn<3, 1, 8, MVP_TN_KT>(a, (hipStream_t)stream);
+#ifndef MVP_TN_NST
+#define MVP_TN_NST 1  // LDS stages (diagnostic builds: tools/tn_bench.py --variants)
+#endif
+    return launch_tn<3, MVP_TN_NST, 8, MVP_TN_KT>(a, (hipStream_t)stream);
   }
   if (a->precision != MVP_PREC_BF16) return MVP_EINVAL;
   return launch_tn<1, 2>(a, (hipStream_t)stream);
