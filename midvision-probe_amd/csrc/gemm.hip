@@ -456,11 +456,10 @@ static bool pp_takes(const mvp_gemm_args* a) {
     if ((long)((a->N + 255) / 256) * 256 * 7 > (long)a->N * 8) return false;  // (narrow outputs: see below)
     return (long)((a->M + 255) / 256) * ((a->N + 255) / 256) >= 512;
   }
-  if (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) {
-    // masked / pair-residual epilogues (the ResNet-50 trunk's residual-adding 1x1 layers: M = 230 400 ... 14 400 rows, K = 64 ... 512 — all
-    // epilogue): the large-M kernel when its universal branch-free epilogue serves the form, by the short-K rule below
-    if (!gemm_epilogue_uni_ok(*a) || (a->tile_policy & (MVP_TILES_NO_UNI | MVP_TILES_NO_PP)) || a->precision != MVP_PREC_BF16X3 || a->pair_layout != MVP_PAIR_SEPARATE) return false;
-  }
+  // masked / pair-residual epilogues of plain GEMMs (the ResNet-50 trunk's residual-adding 1x1 layers: K = 64 ... 512, all epilogue) stay
+  // on the tile kernels: with the universal branch-free epilogue on both, 3-5 resident workgroups per CU keep more bytes in flight than
+  // one persistent 8-wave workgroup (tools/resnet_bench.py, M = 230 400, K = 64, N = 256 + identity: 135 us against 157)
+  if (a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi) return false;
   if (a->pair_layout != MVP_PAIR_SEPARATE) return true;  // only that kernel reads the interleaved layout
   if (a->tile_policy & MVP_TILES_NO_PP) return false;
   if (env >= 0) return env != 0;

@@ -613,7 +613,7 @@ def test_universal_epilogue_bits_equal_the_row_guarded_one(dev, shape):
     }
     for name, f in forms.items():
         outs = {}
-        for pol_name, pol in (("tile_generic", lib.TILES_NO_PP | lib.TILES_NO_UNI), ("tile_uni", lib.TILES_NO_PP), ("auto_uni", 0)):
+        for pol_name, pol in (("tile_generic", lib.TILES_NO_PP | lib.TILES_NO_UNI), ("tile_uni", lib.TILES_NO_PP), ("pp_uni", 0)):
             o32 = torch.full((M, N), float("nan"), device=dev) if f.get("f32") else None
             op = ops.empty_pair((M, N), 3, dev) if f.get("pair") else None
             if op is not None:
@@ -631,13 +631,14 @@ def test_universal_epilogue_bits_equal_the_row_guarded_one(dev, shape):
                 args.residual_lo = None if f["respair"] == "hi" else lib.ptr(rp[1])
             args.act_after_res = int(bool(f.get("act_after")))
             args.tile_policy = pol
-            lib.check(so.mvp_gemm_bias_act_res(C.byref(args), lib.stream_ptr()), f"{name}/{pol_name}")
+            # ("pp_uni": the large-M kernel called directly — the dispatcher keeps masked / pair-residual plain GEMMs on the tile kernels)
+            lib.check((so.mvp_gemm_pp if pol_name == "pp_uni" else so.mvp_gemm_bias_act_res)(C.byref(args), lib.stream_ptr()), f"{name}/{pol_name}")
             torch.cuda.synchronize()
             outs[pol_name] = (o32, op, om)
         ref = outs["tile_generic"]
         if ref[0] is not None:
             assert torch.isfinite(ref[0]).all()
-        for pol_name in ("tile_uni", "auto_uni"):
+        for pol_name in ("tile_uni", "pp_uni"):
             got = outs[pol_name]
             if ref[0] is not None:
                 assert torch.equal(got[0], ref[0]), (shape, name, pol_name, "f32")
