@@ -41,8 +41,10 @@ __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint
 }
 // The mixed form of mvp_gemm_args.out_f16_col0: hi = fp16(v) (rne), lo = bf16(v - hi), two values packed like split2_bf16.
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// hi saturates at the largest finite fp16 (one v_med3 per value): an activation outlier beyond 65504 then keeps hi finite and leaves its excess
+// to lo, which has fp32's exponent range (hi + lo still carries the value to bf16's 8 bits) instead of turning the whole GEMM row into NaN.
 __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)a, (_Float16)b};
+  const f16x2_t h = {(_Float16)__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), (_Float16)__builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
   hi = __builtin_bit_cast(uint32_t, h);
   const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
   lo = __builtin_bit_cast(uint32_t, l);

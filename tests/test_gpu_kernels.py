@@ -682,6 +682,28 @@ def test_gemm_pp_interleaved_layouts_match_separate(dev, shape):
     assert ((base[0].double() + base[1].double() - r).norm() / r.norm()).item() < 7e-5
 
 
+def test_f16_hi_pair_saturates_instead_of_overflowing(dev):
+    """The fp16-hi / bf16-lo pair (MVP_PREC_F16X2 activations): a value beyond fp16's range keeps a FINITE hi (65504) and leaves the excess
+    to lo (bf16: fp32's exponent range), so hi + lo still represents it (to bf16's 8 bits) and a GEMM over such a row stays finite."""
+    from mvp import lib, ops
+
+    M, Cd = 64, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, Cd, generator=g)
+    gam = torch.ones(Cd)
+    gam[5] = 3.0e5  # LayerNorm output column 5 = (x - mean) * rstd * 3e5: far beyond 65504
+    out = ops.empty_pair((M, Cd), lib.PREC_BF16X3, dev)
+    o32 = torch.empty(M, Cd, device=dev)
+    ops.layernorm(x.to(dev), gam.to(dev), torch.zeros(Cd).to(dev), out, M, Cd, 1e-6, out_f32=o32, out_f16=True)
+    torch.cuda.synchronize()
+    hi, lo = out[0].view(torch.float16).float(), out[1].float()
+    assert torch.isfinite(hi).all() and torch.isfinite(lo).all() and hi.abs().max().item() == 65504.0
+    val = hi + lo
+    big = o32.abs() > 65504
+    assert big.any() and ((val - o32).abs()[big] / o32.abs()[big]).max().item() < 2 ** -8
+    assert ((val - o32).abs()[~big] / o32.abs()[~big].clamp_min(1e-3)).max().item() < 1e-5
+
+
 def test_layernorm_and_attention_interleaved_outputs_match_separate(dev):
     """LayerNorm and attention writing their output pair hi|lo-interleaved (the A operand of the large-M GEMM) = the separate pair, bit for bit."""
     from mvp import lib, ops

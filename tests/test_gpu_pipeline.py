@@ -554,6 +554,35 @@ def test_epochs_reuse_the_models_cached_pipeline_and_rebind_to_new_shapes():
     assert len(cached_pipelines(copy.deepcopy(model))) == 0  # nothing of the pipelines hangs on the module itself
 
 
+def test_replayed_forwards_keep_their_token_packings_registered_across_other_pipelines(monkeypatch):
+    """The probe head finds the token-major packing of a feature list through ``mvp.vit.lookup_pack``; a graph replay does not run the host
+    code that registers it.  With the registry squeezed to what ONE pipeline needs (2 slots x 8 batches per forward), a validation pass
+    (its own pipeline, its own packings) between two training epochs ages the training pipeline's entries out — the replay must bring them back (``FeaturePipeline._forward``
+    re-registers its packings), else the head would silently re-pack the NCHW maps on every step from then on."""
+    from evals.models.dino import DINO
+    from mvp import backbone as bb
+    from mvp import vit
+    from mvp.pipeline import pipelined_features
+
+    dev = torch.device("cuda:0")
+    model = DINO(return_multilayer=True, add_norm=True, weights=bb.random_vit_state_dict(seed=3)).to(dev)
+    bs = _batches(dev, 16, B=4, hw=(32, 48))
+    monkeypatch.setattr(vit, "_PACK_REGISTRY_MAX", 16)
+
+    def epoch():
+        hits = 0
+        for _, f in pipelined_features(model, bs):
+            hits += int(vit.lookup_pack(f) is not None)
+        return hits
+
+    model.train()
+    assert epoch() == len(bs)
+    model.eval()
+    assert epoch() == len(bs)  # the eval pipeline's packings push the training pipeline's out of the 16-entry registry
+    model.train()
+    assert epoch() == len(bs)  # replays only: every packing is found again
+
+
 def test_default_span_of_the_timed_configuration():
     """B = 16 at 224^2 on ViT-B/16: 110 images per forward (21670 rows = 85 x 3 tiles of 256^2: one round of 256 CUs for the
     N = 768 GEMMs); 480x640 (1201 rows per image): single batches on three streams, as before (measured faster than 18-image spans)."""
