@@ -143,9 +143,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step (reference default batch_size: 16)")
     ap.add_argument("--image-size", default="224", help="S or HxW (480x640 = BASELINE config #2)")
     ap.add_argument("--precision", default=os.environ.get("MVP_BENCH_PRECISION", "f16x2"), choices=["bf16x3", "f16x2", "bf16"],
-                    help="arithmetic of the frozen ViT blocks' GEMMs.  f16x2 (the benchmarked default since round 4): two MFMA products per contraction — fp16 hi + bf16 lo "
-                         "activations against fp16 / bf16 roundings of the frozen weights — 2.5e-4 ... 4.0e-4 rel-L2 on every ViT-B/16 golden of the reference "
-                         "(tests/test_gpu_kernels.py::test_vit_base_*: the contract is 1e-3); bf16x3 (the library's default): three products, 1.5e-5 ... 2.3e-5, "
+                    help="arithmetic of the frozen ViT blocks' GEMMs.  f16x2 (the library's and this benchmark's default since round 4): two fp16 MFMA products per contraction over compensated fp16 pairs "
+                         "(include/mvp_hip.h, MVP_PREC_F16X2: the weight's fp16 rounding error rides in the second product) — 1.5e-5 ... 2.3e-5 rel-L2 on every ViT-B/16 golden "
+                         "of the reference, the same as bf16x3 (tests/test_gpu_kernels.py::test_vit_base_*: the contract is 1e-3); bf16x3: three bf16 products, the same error, "
                          "timed in the same run and reported as `precision_bf16x3`; bf16: one product, fails the contract (4-6e-3)")
     ap.add_argument("--no-alt-precision", action="store_true", help="skip the extra bf16x3 leg of an f16x2 run")
     ap.add_argument("--probe-precision", default="bf16x3", choices=["bf16x3", "bf16"],
@@ -443,7 +443,7 @@ def main():
                      "host_throttle_wait_ms_per_step": round(host_wait / args.sustained_steps * 1e3, 4),
                      "host_work_ms_per_step": round((host_dt - host_wait) / args.sustained_steps * 1e3, 4)}
 
-    # ---------------- the same timed region in the library's default precision (three products): reported next to `value`, never instead of it
+    # ---------------- the same timed region in the three-product arithmetic (MVP_PRECISION=bf16x3): reported next to `value`, never instead of it
     alt_precision = None
     if args.precision == "f16x2" and not args.no_alt_precision and not args.pmc_child and world == 1:
         model_b = DINO(return_multilayer=True, add_norm=True, weights=vsd, precision="bf16x3").to(dev)
@@ -458,7 +458,7 @@ def main():
         barrier()
         bdt = time.perf_counter() - tb
         alt_precision = {"precision": "bf16x3", "steps": args.steps, "value": round(B * args.steps / bdt, 2), "unit": "images/s", "ms_per_step": round(bdt / args.steps * 1e3, 4),
-                         "note": "the library's default arithmetic (three MFMA products per contraction, 1.5e-5 ... 2.3e-5 on the reference's ViT-B/16 goldens), "
+                         "note": "MVP_PRECISION=bf16x3 (three bf16 MFMA products per contraction, fp32's exponent range; the same 1.5e-5 ... 2.3e-5 on the reference's ViT-B/16 goldens as f16x2), "
                                  "same pipeline, same timed-region rules, same process"}
         del model_b, pipe_b, objs_b
         torch.cuda.empty_cache()
@@ -598,7 +598,7 @@ def main():
             "regime": "timed: HIP events around every launch (on the stream it is launched on) while the pipeline runs as in the timed region — "
                       f"{pipe.group} batches per frozen forward on {pipe.chains} side stream(s), the probe steps of the previous batches beside it; eager launches instead of graph replay",
             "note": ("algorithmic 2*M*N*K flops (bf16x3 issues 3 MFMA passes per algorithmic flop: x3 = share of the bf16 MFMA pipe)" if args.precision == "bf16x3" else
-                     "algorithmic 2*M*N*K flops (f16x2 issues 2 MFMA passes — one f16, one bf16, same rate — per algorithmic flop: x2 = share of the MFMA pipe)" if args.precision == "f16x2" else
+                     "algorithmic 2*M*N*K flops (f16x2 issues 2 f16 MFMA passes — the bf16 pipe's rate — per algorithmic flop: x2 = share of the MFMA pipe)" if args.precision == "f16x2" else
                      "algorithmic 2*M*N*K flops, one bf16 MFMA pass each"),
             "kernel_alone": None if not ka else {"avg_launch_us": round(ka[1] / ka[2] * 1e6, 2), "alg_tflops": round(ka[0] / ka[1] / 1e12, 2), "frac": round(ka[0] / ka[1] / 1e12 / 2500.0, 4),
                                                  "note": "the same launches with nothing beside them (forwards only, one stream): what rocprofv3 --kernel-trace reports too"},
@@ -682,7 +682,7 @@ def main():
             "dist_backend": backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA, three products per contraction, fp32 accumulate; fp32 residual/LN/softmax/loss)",
-                      "f16x2": "f16x2 (fp16-hi + bf16-lo activations x fp16 / bf16 frozen weights, two MFMA products per contraction, fp32 accumulate; attention scores, "
+                      "f16x2": "f16x2 (compensated fp16 pairs of activations and frozen weights, two f16 MFMA products per contraction, fp32 accumulate, feature error as bf16x3; attention scores, "
                                "probe, fp32 residual/LN/softmax/loss as in bf16x3)",
                       "bf16": "bf16 (MFMA, fp32 accumulate)"}[args.precision],
             "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",

@@ -35,13 +35,19 @@ extern "C" {
 
 #define MVP_PREC_BF16 1   /* one bf16 MFMA pass                              */
 #define MVP_PREC_BF16X3 3 /* three passes (split bf16), ~fp32 operand accuracy */
-#define MVP_PREC_F16X2 2  /* (ABI 6, opt-in) TWO passes per contraction of mvp_gemm_bias_act_res / mvp_gemm_pp (plain linear GEMMs only):
-                             the activation operand is a pair hi = fp16(a), lo = bf16(a - hi) (what LayerNorm / attention / a GEMM epilogue
-                             write under their out_f16 / out_f16_col0 switches), the weight operand holds hi = fp16(w), lo = bf16(w) — two
-                             roundings of the SAME value — and the product runs as  a_lo . bf16(w)  (bf16 MFMA)  +  a_hi . fp16(w)  (f16
-                             MFMA), fp32 accumulate.  Operand error: the activation to 2^-20, the weight to 2^-12 (one fp16 rounding of a frozen
-                             weight).  2/3 of the matrix-pipe work of BF16X3 on a chip whose clock is held down by exactly that work
-                             (the large-M kernel: -19 % time); measured feature error in tests/test_gpu_kernels.py (ViT goldens).      */
+#define MVP_PREC_F16X2 2  /* (ABI 6, opt-in) TWO fp16 passes per contraction of mvp_gemm_bias_act_res / mvp_gemm_pp (plain linear GEMMs only), with the
+                             weight's fp16 rounding error carried by the second pass ("compensated" pairs).  With s = 2^-6:
+                               activation  a_hi = fp16(a),            a_lo = fp16(8 (a - a_hi) + a_hi / 8)       (LayerNorm / attention out_f16 = 1,
+                                                                                                                  a GEMM epilogue's out_f16_col0 = -1)
+                               weight      w_hi = fp16((1 - s) w),    w_lo = fp16((w + d / s) / 8),  d = (1 - s) w - w_hi    (built once, frozen)
+                             and the product runs as  a_lo . w_lo + a_hi . w_hi  (two f16 MFMAs, fp32 accumulate).  Exactly:
+                               a_hi w_hi + a_lo w_lo = a_hi ((1 - s) w - d) + ((a - a_hi) + s a_hi) (w + d / s) = a w + (a - a_hi) d / s,
+                             i.e. the s a_hi w that the first pass leaves out and its rounding error d both ride in the second; what is left is
+                             (a - a_hi) d / s <= 2^-12 * 2^-6 |a w| plus the fp16 roundings of a_lo and w_lo (2^-18 each) — the accuracy class of
+                             BF16X3 (tests/test_gpu_kernels.py measures it against fp64, with the ViT goldens' feature error) at 2/3 of its
+                             matrix-pipe work, on a chip whose clock is held down by exactly that work (the large-M kernel: -19 % time).
+                             Range: |a| <= 65504 (hi and lo saturate there; beyond it the result is wrong, not NaN); values whose lo half falls
+                             below fp16's normal range (|a| < 5e-4, |w| < 5e-4) keep absolute, not relative, precision.                     */
 
 #define MVP_ACT_NONE 0
 #define MVP_ACT_GELU 1 /* exact erf GELU (torch nn.GELU default)            */
@@ -162,8 +168,9 @@ typedef struct {
    * [rows][N / 32][hi 32 | lo 32] with row stride ldob (2 * N when dense), out_lo is ignored, N % 32 == 0 — the A operand of a following
    * large-M GEMM (fc1 -> fc2).  Any kernel of mvp_gemm_bias_act_res writes it.                                                        */
   int out_pair_layout;
-  /* --- mixed 16-bit forms inside the bf16-pair output (ABI 6): out_f16_col0 > 0 (a multiple of 64; or -1: every column; MVP_PREC_BF16X3 / F16X2,
-   * out_hi and a lo half required): columns >= out_f16_col0 are written as hi = fp16(v) (round to nearest even), lo = bf16(v - hi) instead of
+  /* --- 16-bit forms other than the bf16 pair inside the pair output (ABI 6; MVP_PREC_BF16X3 / F16X2, out_hi and a lo half required).
+   * out_f16_col0 = -1: EVERY column is written as the activation pair of MVP_PREC_F16X2 above (fc1 -> fc2).
+   * out_f16_col0 > 0 (a multiple of 64): columns >= out_f16_col0 are written as hi = fp16(v) (round to nearest even), lo = bf16(v - hi) instead of
    * hi = bf16(v), lo = bf16(v - hi) — the V third of the fused qkv projection (out_f16_col0 = 2 * H * 64), which the attention
    * kernel multiplies with probabilities held as ONE fp16 value (mvp_attention_args.v_format).  Same 2 + 2 bytes, same arrays and
    * layouts; |v - hi - lo| <= 2^-20 |v|.  Every kernel of mvp_gemm_bias_act_res / mvp_gemm_pp writes it (not stream-K).        */
@@ -202,7 +209,7 @@ typedef struct {
   float eps;
   int out_layout;                     /* MVP_PAIR_SEPARATE, or MVP_PAIR_A_ILV32 (1): out_hi is ONE [M][C / 32][hi 32 | lo 32] array (row stride
                                          2 * C), out_lo ignored, C % 32 == 0 — the A operand of the large-M GEMM (mvp_gemm_args.pair_layout) */
-  int out_f16;                        /* (ABI 6) 1: the pair is written as hi = fp16(y), lo = bf16(y - hi): the activation operand of MVP_PREC_F16X2 */
+  int out_f16;                        /* (ABI 6) 1: the pair is written as the activation operand of MVP_PREC_F16X2 (hi = fp16(y), lo = fp16(8 (y - hi) + hi / 8)) */
 } mvp_layernorm_args;
 int mvp_layernorm_fwd(const mvp_layernorm_args*, void* stream);
 
@@ -229,7 +236,7 @@ typedef struct {
                        instead of three and no hi / lo split of P on the vector pipe (the kernel is VALU-bound); the online softmax
                        rescales its running maximum only when it rises by more than 2^6.  Q.K^T keeps its three products either way.
                        Relative error of the output: ~2^-12 per probability (random, averaged over the keys) instead of 2^-17.        */
-  int out_f16;      /* (ABI 6) 1: the output pair is written as hi = fp16(o), lo = bf16(o - hi): the activation operand of a MVP_PREC_F16X2 proj GEMM */
+  int out_f16;      /* (ABI 6) 1: the output pair is written as the activation operand of a MVP_PREC_F16X2 proj GEMM (hi = fp16(o), lo = fp16(8 (o - hi) + hi / 8)) */
 } mvp_attention_args;
 #define MVP_ATT_V_BF16_PAIR 0
 #define MVP_ATT_V_F16 1

@@ -269,9 +269,9 @@ __device__ __forceinline__ void attn_store(AttnState<SPLIT>& st, const mvp_atten
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint32_t h01, l01, h23, l23;
-      if (p.out_f16) {  // hi = fp16, lo = bf16: the activation operand of a two-product (MVP_PREC_F16X2) proj GEMM
-        split2_f16_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
-        split2_f16_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
+      if (p.out_f16) {  // the compensated fp16 pair: the activation operand of a two-product (MVP_PREC_F16X2) proj GEMM
+        split2_f16_comp(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
+        split2_f16_comp(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);
       } else {
         split2_bf16(st.o_acc[dt][qt][0] * inv, st.o_acc[dt][qt][1] * inv, h01, l01);
         split2_bf16(st.o_acc[dt][qt][2] * inv, st.o_acc[dt][qt][3] * inv, h23, l23);

@@ -223,8 +223,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_kernel(const mvp_gemm_args p) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          if (SPLIT == 2) {  // MVP_PREC_F16X2: a_lo . bf16(w), then a_hi . fp16(w) (the order gemm_pp.hip uses)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_lo[j], acc[i][j], 0, 0, 0);
+          if (SPLIT == 2) {  // MVP_PREC_F16X2: two fp16 products, lo . lo then hi . hi (the order gemm_pp.hip uses)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w_lo[i]), __builtin_bit_cast(f16x8_t, a_lo[j]), acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w_hi[i]), __builtin_bit_cast(f16x8_t, a_hi[j]), acc[i][j], 0, 0, 0);
             continue;
           }

@@ -194,7 +194,10 @@ __device__ __forceinline__ void gemm_epilogue(const ARGS& p, f32x4_t (&acc)[NT][
           for (int e = 0; e < 4; ++e) v[e] *= keep[e];  // (out_f32 above stayed un-gated)
         }
         uint32_t h01, l01, h23, l23;
-        if (p.out_f16_col0 != 0 && ncol >= p.out_f16_col0) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv / every column (-1); 4 columns: all in or all out
+        if (p.out_f16_col0 < 0) {  // every column as the activation operand of a MVP_PREC_F16X2 GEMM (the compensated fp16 pair)
+          split2_f16_comp(v[0], v[1], h01, l01);
+          split2_f16_comp(v[2], v[3], h23, l23);
+        } else if (p.out_f16_col0 != 0 && ncol >= p.out_f16_col0) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv; 4 columns: all in or all out
           split2_f16_bf16(v[0], v[1], h01, l01);
           split2_f16_bf16(v[2], v[3], h23, l23);
         } else {
@@ -374,7 +377,10 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
       }
       if (PAIR) {
         uint32_t hw[4], lw[4];
-        if (f16_cols) {  // (wave-uniform: out_f16_col0 % 64 == 0)
+        if (p.out_f16_col0 < 0) {  // (-1: every column, the compensated fp16 pair)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16_comp(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
+        } else if (f16_cols) {  // (wave-uniform: out_f16_col0 % 64 == 0)
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_f16_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
         } else {
@@ -553,7 +559,10 @@ __device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[
       __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][4]), f2u(v[it][5]), f2u(v[it][6]), f2u(v[it][7])}, r_o32, ro[it].o32, 16, 0);
       uint32_t hw[4] = {0u, 0u, 0u, 0u}, lw[4] = {0u, 0u, 0u, 0u};
       if (has_pair) {
-        if (f16_cols) {
+        if (p.out_f16_col0 < 0) {  // (-1: every column, the compensated fp16 pair)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16_comp(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
+        } else if (f16_cols) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_f16_bf16(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
         } else {

@@ -95,10 +95,11 @@ constexpr int PP_SMEM = 2 * PP_BUF_B;    // two k-step buffers = 128 KiB
 //   * no workgroup exit / dispatch / kernel-argument load between the tiles of a CU.
 // Only the wide epilogues (no other loads in flight but the residual's) prefetch across the epilogue; the generic epilogue (masks, second
 // residuals: the DPT convolutions, K >= 1152 there) keeps its 70 KB scratch at the start of LDS and re-runs the cold prologue per tile.
-// F16X2 (MVP_PREC_F16X2): two products per fragment pair instead of three — the activation pair is hi = fp16, lo = bf16, the weight
-// "pair" holds fp16(w) and bf16(w): acc += a_lo . bf16(w) (bf16 MFMA), then acc += a_hi . fp16(w) (f16 MFMA).  Same arrays, layouts,
-// staging and fragment reads (the halves are 16-bit either way); per 32-deep k-step lo product first, then hi, k ascending — the
-// order the tile kernels use, so the two families stay bit-identical in this mode too.
+// F16X2 (MVP_PREC_F16X2): two products per fragment pair instead of three — both operands are the compensated fp16 pairs of
+// include/mvp_hip.h (activation: hi = fp16(a), lo = fp16(8 (a - hi) + hi / 8); weight: hi = fp16((1 - 2^-6) w), lo = fp16((w + 64 d) / 8)):
+// acc += a_lo . w_lo, then acc += a_hi . w_hi, both f16 MFMAs.  Same arrays, layouts, staging and fragment reads (the halves are
+// 16-bit either way); per 32-deep k-step lo product first, then hi, k ascending — the order the tile kernels use, so the two families
+// stay bit-identical in this mode too.
 template <bool ILVA, bool ILVW, bool EXT, bool CONV = false, bool F16X2 = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
   static_assert(!(CONV && ILVA), "the convolution reads separate hi / lo activation arrays");
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const mvp_gemm_args p) {
       for (int j = 0; j < 4; ++j) {
         f32x4_t c = acc[i][half * 4 + j];
         if constexpr (F16X2) {
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[i], a_lo[j], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w_lo[i]), __builtin_bit_cast(f16x8_t, a_lo[j]), c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, w_hi[i]), __builtin_bit_cast(f16x8_t, a_hi[j]), c, 0, 0, 0);
           acc[i][half * 4 + j] = c;
           continue;
@@ -538,7 +539,10 @@ inline int pp_grid(const mvp_gemm_args* a) {
   // persistent grid: one workgroup per CU (128 KB of LDS each), tiles dealt round by round; MVP_PP_PERSIST=0 (diagnostic): one tile
   // per workgroup, the pre-round-4 launch.  (A multiple of 8 keeps a workgroup's tiles on one XCD slice of the region order.)
   static const int persist = [] { const char* e = getenv("MVP_PP_PERSIST"); return (e ? atoi(e) : 1) && !MVP_PP_NOLOOP; }();
-  const int cus = pp_cu_count() & ~7;
+  // MVP_PP_GRID=n (diagnostic): at most n workgroups per launch — a share of the chip, for forward chains running side by side
+  static const int cap = [] { const char* e = getenv("MVP_PP_GRID"); return e ? atoi(e) & ~7 : 0; }();
+  int cus = pp_cu_count() & ~7;
+  if (cap >= 8 && cap < cus) cus = cap;
   return (persist && cus >= 8 && tiles > cus) ? cus : tiles;
 }
 

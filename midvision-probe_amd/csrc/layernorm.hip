@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
       uint32_t h[4], l[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (p.out_f16) split2_f16_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
+        if (p.out_f16) split2_f16_comp(y[2 * e], y[2 * e + 1], h[e], l[e]);
         else split2_bf16(y[2 * e], y[2 * e + 1], h[e], l[e]);
       }
       if (p.out_layout == MVP_PAIR_A_ILV32) {  // one array, hi | lo interleaved per 32 columns (an 8-element chunk never straddles a block)

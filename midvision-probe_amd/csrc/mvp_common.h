@@ -49,6 +49,18 @@ __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, 
   const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// The ACTIVATION operand of MVP_PREC_F16X2 (the "compensated" pair; include/mvp_hip.h has the algebra): hi = fp16(v) (rne, saturating like
+// split2_f16_bf16), lo = fp16(8 * (v - hi) + hi / 8) — v - hi, hi / 8 and their sum are exact in fp32 (17 significant bits), so lo has ONE
+// rounding.  Against the weight pair (fp16((1 - 2^-6) w), fp16((w + 64 d) / 8)), d = (1 - 2^-6) w - hi_w, the two fp16 products sum to
+// v * w + (v - hi) * 64 d: relative error ~2^-18 per term instead of the 2^-12 of a single fp16 rounding of w.
+__device__ __forceinline__ void split2_f16_comp(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const f16x2_t h = {(_Float16)__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), (_Float16)__builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
+  hi = __builtin_bit_cast(uint32_t, h);
+  const float ha = (float)h[0], hb = (float)h[1];
+  const float la = __builtin_fmaf(a - ha, 8.f, ha * 0.125f), lb = __builtin_fmaf(b - hb, 8.f, hb * 0.125f);
+  const f16x2_t l = {(_Float16)__builtin_fminf(__builtin_fmaxf(la, -65504.f), 65504.f), (_Float16)__builtin_fminf(__builtin_fmaxf(lb, -65504.f), 65504.f)};
+  lo = __builtin_bit_cast(uint32_t, l);
+}
 // Bit pattern <-> float through a SCALAR.  (ROCm 7.2's clang miscompiles __builtin_bit_cast(float, vec[e]) written directly on an
 // element of an ext_vector: every e yields element 0 — the optimiser then narrows a 16-byte load to its first dword.  Passing the
 // element by value makes it a scalar first.)

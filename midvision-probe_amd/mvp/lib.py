@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MVP_LIB") or os.path.join(os.path.dirname(_HERE), "cs
 
 PREC_BF16 = 1
 PREC_BF16X3 = 3
-PREC_F16X2 = 2  # two products per GEMM contraction (fp16 hi + bf16 lo activations, fp16 / bf16 roundings of the weights): mvp_hip.h
+PREC_F16X2 = 2  # two fp16 products per GEMM contraction over compensated fp16 pairs (ops.split_f16_comp / ops.f16x2_weight): mvp_hip.h
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BICUBIC = 0, 1, 2
 PAIR_SEPARATE, PAIR_A_ILV32, PAIR_W_ILV32 = 0, 1, 2  # mvp_gemm_args.pair_layout (bit flags)

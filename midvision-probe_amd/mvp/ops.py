@@ -112,18 +112,34 @@ def split_bf16(src: torch.Tensor, precision: int = PREC_BF16X3) -> Pair:
     return hi, lo
 
 
+F16X2_S = 2.0 ** -6  # the share of the hi product that PREC_F16X2 moves into the lo product (include/mvp_hip.h, MVP_PREC_F16X2)
+
+
 def f16x2_weight(w: torch.Tensor) -> Pair:
-    """The weight operand of a PREC_F16X2 GEMM: (fp16(w) — its bits in a bf16-typed array, like every pair half of this library —,
-    bf16(w)): two roundings of the same value, the partners of the activation's fp16 hi and bf16 lo halves."""
-    w = w.detach().float().contiguous()
-    return w.half().view(torch.bfloat16), w.bfloat16()
+    """The weight operand of a PREC_F16X2 GEMM (include/mvp_hip.h): hi = fp16((1 - s) w), lo = fp16((w + d / s) / 8) with
+    d = (1 - s) w - hi — fp16 bits in bf16-typed arrays, like every pair half of this library.  fp64 arithmetic: one rounding each."""
+    w = w.detach().double().contiguous()
+    t = (1.0 - F16X2_S) * w
+    hi = t.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = ((w + (t - hi.double()) / F16X2_S) / 8.0).clamp(-65504.0, 65504.0).to(torch.float16)
+    return hi.view(torch.bfloat16).contiguous(), lo.view(torch.bfloat16).contiguous()
+
+
+def split_f16_comp(src: torch.Tensor) -> Pair:
+    """fp32 -> the activation pair of a PREC_F16X2 GEMM: hi = fp16(x), lo = fp16(8 (x - hi) + hi / 8), both saturating at +-65504
+    (bits in bf16-typed arrays).  (torch ops: tests and one-off conversions; the kernels write this form themselves.)"""
+    x = src.float()
+    hi = x.clamp(-65504.0, 65504.0).half()
+    h = hi.float()
+    lo = ((x - h) * 8.0 + h * 0.125).clamp(-65504.0, 65504.0).half()
+    return hi.view(torch.bfloat16).contiguous(), lo.view(torch.bfloat16).contiguous()
 
 
 def split_f16_bf16(src: torch.Tensor) -> Pair:
-    """fp32 -> the activation pair of a PREC_F16X2 GEMM: hi = fp16(x) (bits in a bf16-typed array), lo = bf16(x - hi).  (torch ops: tests
-    and one-off conversions; the kernels write this form themselves.)"""
+    """fp32 -> hi = fp16(x) (bits in a bf16-typed array, saturating), lo = bf16(x - hi): the form of the V third under
+    ``gemm(..., f16_col0=2 * H * 64)``.  (torch ops: tests.)"""
     x = src.float()
-    hi = x.half()
+    hi = x.clamp(-65504.0, 65504.0).half()
     return hi.view(torch.bfloat16).contiguous(), (x - hi.float()).bfloat16().contiguous()
 
 
@@ -209,7 +225,8 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
          w_ilv: Optional[torch.Tensor] = None, f16_col0: int = 0) -> None:
     """Y = act(A Wᵀ + bias) + residual (see mvp_gemm_bias_act_res).  splitk: None = automatic, 1 = off.
     f16_col0 > 0: columns from there on of the pair output are written as hi = fp16, lo = bf16 (mvp_gemm_args.out_f16_col0: the V
-    third of the fused qkv projection for ``attention(..., v_f16=True)``); no split-K / stream-K then.
+    third of the fused qkv projection for ``attention(..., v_f16=True)``); f16_col0 = -1: EVERY column as the activation operand of a
+    PREC_F16X2 GEMM (``split_f16_comp``'s form: fc1 -> fc2); no split-K / stream-K either way.
     residual_pair: the residual as a bf16 pair (hi, lo) instead of / in addition to the fp32 ``residual``.
     streamk: None = automatic (streamk_auto), True / False force the stream-K kernel on / off.
     w_ilv: the same weights as ``interleave_pair(w)``; handed to the large-M kernel when the dispatch rule picks it."""
@@ -269,7 +286,7 @@ def gemm(a: Pair, w: Pair, M: int, N: int, K: int, *, bias=None, residual=None, 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pair, M: int, Cdim: int, eps: float,
               out_f32: Optional[torch.Tensor] = None, out_f16: bool = False) -> None:
-    """``out_f16``: the pair is written as hi = fp16, lo = bf16 (the activation operand of a PREC_F16X2 GEMM)."""
+    """``out_f16``: the pair is written as the activation operand of a PREC_F16X2 GEMM (``split_f16_comp``'s form)."""
     ilv = isinstance(out, IlvPair)
     if ilv:
         out = (out.t, None)
@@ -283,7 +300,8 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pai
 def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None, v_f16: bool = False,
               out_f16: bool = False) -> None:
     """``v_f16``: the V third of ``qkv`` holds hi = fp16, lo = bf16 (``gemm(..., f16_col0=2 * H * 64)``); the probabilities are then held
-    as one fp16 value (mvp_attention_args.v_format = MVP_ATT_V_F16; bf16x3 only)."""
+    as one fp16 value (mvp_attention_args.v_format = MVP_ATT_V_F16; bf16x3 only).  ``out_f16``: the output pair leaves as the activation
+    operand of a PREC_F16X2 GEMM (``split_f16_comp``'s form)."""
     ilv = isinstance(out, IlvPair)
     if ilv:
         out, ld_out = (out.t, None), (ld_out if ld_out is not None else 2 * H * 64)

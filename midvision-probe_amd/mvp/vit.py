@@ -27,8 +27,8 @@ from .lib import PREC_BF16, PREC_BF16X3
 
 def parse_precision(p) -> int:
     """'bf16x3' (default: three bf16 products per contraction, ~1e-5 on the features), 'f16x2' (opt-in: the four GEMMs of every block
-    with two products — fp16 hi + bf16 lo activations against fp16 / bf16 roundings of the frozen weights; everything else as in bf16x3;
-    ~3e-4 on the features), 'bf16' (one product: fails the 1e-3 feature contract)."""
+    with two fp16 products over compensated fp16 pairs, include/mvp_hip.h MVP_PREC_F16X2; everything else as in bf16x3; the same
+    ~1e-5 on the features, |activation| <= 65504), 'bf16' (one product: fails the 1e-3 feature contract)."""
     if p in (PREC_BF16, PREC_BF16X3, lib.PREC_F16X2):
         return p
     s = str(p).lower()
@@ -152,7 +152,7 @@ class ViTEngine:
                 fc1_w=ops.split_bf16(sd[p + "mlp.fc1.weight"], self.precision), fc1_b=sd[p + "mlp.fc1.bias"],
                 fc2_w=ops.split_bf16(sd[p + "mlp.fc2.weight"], self.precision), fc2_b=sd[p + "mlp.fc2.bias"],
             )
-            if self.f16x2:  # the weight operands of the two-product GEMMs: (fp16(w), bf16(w))
+            if self.f16x2:  # the weight operands of the two-product GEMMs (ops.f16x2_weight: compensated fp16 pairs)
                 for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w"):
                     blk[n] = ops.f16x2_weight(sd[p + {"qkv_w": "attn.qkv.weight", "proj_w": "attn.proj.weight", "fc1_w": "mlp.fc1.weight", "fc2_w": "mlp.fc2.weight"}[n]])
             if self.precision == PREC_BF16X3:  # hi|lo-interleaved copies of the frozen weights for the large-M GEMM kernel (mvp.ops.interleave_pair)
@@ -283,7 +283,7 @@ class ViTEngine:
         # bf16x3: the V third of qkv leaves the GEMM as hi = fp16, lo = bf16, and the attention kernel holds its probabilities as one
         # fp16 value (csrc/attention.hip, VF16; MVP_ATT_V=pair brings back the bf16-pair probabilities of rounds 1-3)
         vf16 = self.att_v_f16
-        # (f16x2: Q and K stay bf16 pairs — Q.K^T keeps its three products —, the attention output and fc1's output leave as fp16 hi + bf16 lo)
+        # (f16x2: Q and K stay bf16 pairs — Q.K^T keeps its three products —, the attention output, LayerNorm's and fc1's output leave as compensated fp16 activation pairs)
         ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=gp, w_ilv=blk.get("qkv_w_ilv"),
                  f16_col0=2 * C if vf16 else 0)
         ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16, out_f16=f2)

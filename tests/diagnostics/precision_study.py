@@ -8,7 +8,8 @@ sys.path.insert(0, REPO)
 import torch, torch.nn.functional as F
 from oracle import vit as ov
 
-MODE = {"fmt": None, "a_split": False, "w_split": False}
+MODE = {"fmt": None, "a_split": False, "w_split": False, "comp": False}
+S = 2.0 ** -6  # MVP_PREC_F16X2's share (include/mvp_hip.h)
 _lin = F.linear
 
 
@@ -26,7 +27,19 @@ def operand(x, split):
     return hi
 
 
+def f16(x):
+    return x.clamp(-65504.0, 65504.0).half().float()
+
+
 def linear(x, w, b=None):
+    if MODE["comp"]:  # MVP_PREC_F16X2: a_hi . w_hi + a_lo . w_lo over the compensated fp16 pairs (the four GEMMs of a block)
+        a_hi = f16(x)
+        a_lo = f16((x - a_hi) * 8.0 + a_hi * 0.125)
+        wd = w.double()
+        w_hi = ((1.0 - S) * wd).half()
+        w_lo = ((wd + ((1.0 - S) * wd - w_hi.double()) / S) / 8.0).half().float()
+        y = _lin(a_hi, w_hi.float()) + _lin(a_lo, w_lo)
+        return y if b is None else y + b
     return _lin(operand(x, MODE["a_split"]), operand(w, MODE["w_split"]), b)
 
 
@@ -66,8 +79,9 @@ def main():
     img = torch.randn(2, 3, size, size)
     res = {}
     for name, fmt, a_s, w_s in (("fp32", None, 0, 0), ("bf16", torch.bfloat16, 0, 0), ("bf16x3~", torch.bfloat16, 1, 1),
-                                ("fp16", torch.float16, 0, 0), ("fp16 a-split", torch.float16, 1, 0), ("fp16 w-split", torch.float16, 0, 1)):
-        MODE.update(fmt=fmt, a_split=bool(a_s), w_split=bool(w_s))
+                                ("fp16", torch.float16, 0, 0), ("fp16 a-split", torch.float16, 1, 0), ("fp16 w-split", torch.float16, 0, 1),
+                                ("f16x2 (comp)", torch.bfloat16, 1, 1)):  # the last: compensated GEMMs, attention operands as bf16 pairs
+        MODE.update(fmt=fmt, a_split=bool(a_s), w_split=bool(w_s), comp=name.startswith("f16x2"))
         with torch.no_grad():
             res[name] = run(sd, img, scale)
     ref = res["fp32"]

@@ -526,10 +526,11 @@ def test_gemm_pp_tile_loop_and_wide_epilogues_equal_the_tile_kernels(dev, shape)
 
 @pytest.mark.parametrize("shape", [(3152, 2304, 768), (3152, 768, 3072), (21670, 3072, 768), (21670, 768, 768), (700, 768, 128)])
 def test_gemm_two_product_mode_vs_fp64_and_across_kernel_families(dev, shape):
-    """MVP_PREC_F16X2 (opt-in): activations as hi = fp16 + lo = bf16, weights as (fp16(w), bf16(w)), two MFMAs per fragment pair.
-    Against fp64 of the EXACT operands: the only error is the fp16 rounding of the weights (2^-12 each, random: <= 2.5e-4 rel-L2 here;
-    the three-product mode: 1e-5) — printed.  The tile kernels and the large-M kernel (separate and interleaved operands, interleaved
-    output, fp16-hi output columns) return the same bits, as in the three-product mode."""
+    """MVP_PREC_F16X2 (opt-in): two f16 MFMAs per fragment pair over the compensated fp16 pairs of include/mvp_hip.h (activation
+    hi = fp16(a), lo = fp16(8 (a - hi) + hi / 8); weight hi = fp16((1 - 2^-6) w), lo = fp16((w + 64 d) / 8)).  Against fp64 of the fp32
+    operands: what is left is (a - hi) * 64 d and the roundings of the two lo halves — <= 2e-5 rel-L2 asserted (the three-product mode:
+    ~5e-6 to 1e-5; one fp16 rounding of the weights would be 2e-4) — printed.  The tile kernels and the large-M kernel (separate and
+    interleaved operands, interleaved output, compensated output columns) return the same bits, as in the three-product mode."""
     import ctypes as C
 
     from mvp import lib, ops
@@ -539,10 +540,14 @@ def test_gemm_two_product_mode_vs_fp64_and_across_kernel_families(dev, shape):
     a = torch.randn(M, K, generator=g).to(dev)
     w = (torch.randn(N, K, generator=g) * 0.05).to(dev)
     bias, res = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
-    ap, wp = ops.split_f16_bf16(a), ops.f16x2_weight(w)
-    a_exact = ap[0].view(torch.float16).double() + ap[1].double()
-    assert ((a_exact - a.double()).abs().max() / a.abs().max()).item() < 2e-6  # the activation pair carries ~20 bits
-    ref = a_exact @ w.double().t() + bias.double()
+    ap, wp = ops.split_f16_comp(a), ops.f16x2_weight(w)
+
+    def decode(pair):  # hi + (lo - hi / 8) / 8
+        h = pair[0].view(torch.float16).double()
+        return h + (pair[1].view(torch.float16).double() - h / 8) / 8
+
+    assert ((decode(ap) - a.double()).abs().max() / a.abs().max()).item() < 2 ** -16  # the activation pair carries ~17 bits of a
+    ref = a.double() @ w.double().t() + bias.double()
     so = lib.load()
     for form, act, use_res in (("pair", lib.ACT_GELU, False), ("f32", lib.ACT_NONE, True)):
         r = F.gelu(ref) if act == lib.ACT_GELU else ref
@@ -562,14 +567,14 @@ def test_gemm_two_product_mode_vs_fp64_and_across_kernel_families(dev, shape):
                                 M, N, K, 2 * K if ai is not None else K, 2 * K if wi is not None else K, N, N, N, act, lib.PREC_F16X2, 0, 0, 0, 0)
             args.pair_layout = 3 if pol == "pp_ilv" else 0
             args.tile_policy = lib.TILES_NO_PP if pol == "tile" else 0
-            args.out_f16_col0 = -1 if form == "pair" else 0  # the pair leaves as fp16 hi + bf16 lo (fc1's output in this mode)
+            args.out_f16_col0 = -1 if form == "pair" else 0  # the pair leaves as the next GEMM's activation operand (fc1's output in this mode)
             lib.check((so.mvp_gemm_bias_act_res if pol == "tile" else so.mvp_gemm_pp)(C.byref(args), lib.stream_ptr()), pol)
             torch.cuda.synchronize()
-            val = out.double() if out is not None else op[0].view(torch.float16).double() + op[1].double()
+            val = out.double() if out is not None else decode(op)
             err = ((val - r).norm() / r.norm()).item()
             if pol == "tile":
                 print(f"\n[gemm f16x2 M,N,K={shape} {form}] rel-L2 vs fp64: {err:.2e}")
-            assert err < 2.5e-4, (shape, pol, form, err)
+            assert err < 2e-5, (shape, pol, form, err)
             outs[pol] = (out, op)
         for pol in outs:
             if form == "f32":
@@ -682,9 +687,13 @@ def test_gemm_pp_interleaved_layouts_match_separate(dev, shape):
     assert ((base[0].double() + base[1].double() - r).norm() / r.norm()).item() < 7e-5
 
 
-def test_f16_hi_pair_saturates_instead_of_overflowing(dev):
-    """The fp16-hi / bf16-lo pair (MVP_PREC_F16X2 activations): a value beyond fp16's range keeps a FINITE hi (65504) and leaves the excess
-    to lo (bf16: fp32's exponent range), so hi + lo still represents it (to bf16's 8 bits) and a GEMM over such a row stays finite."""
+def test_f16_pairs_saturate_instead_of_overflowing(dev):
+    """The fp16 forms of a pair hold FINITE halves for values beyond fp16's range.  The compensated activation pair (LayerNorm out_f16):
+    hi = +-65504 and a finite lo — the value is wrong there (documented range of MVP_PREC_F16X2) but a GEMM over such a row stays finite;
+    inside the range hi + (lo - hi / 8) / 8 returns the value to 2^-16.  The fp16-hi / bf16-lo form of the V third (a GEMM epilogue's
+    out_f16_col0 > 0): hi = 65504 and the excess in lo (bf16: fp32's exponent range), so hi + lo still carries the value to bf16's 8 bits."""
+    import ctypes as C
+
     from mvp import lib, ops
 
     M, Cd = 64, 256
@@ -696,12 +705,31 @@ def test_f16_hi_pair_saturates_instead_of_overflowing(dev):
     o32 = torch.empty(M, Cd, device=dev)
     ops.layernorm(x.to(dev), gam.to(dev), torch.zeros(Cd).to(dev), out, M, Cd, 1e-6, out_f32=o32, out_f16=True)
     torch.cuda.synchronize()
-    hi, lo = out[0].view(torch.float16).float(), out[1].float()
+    hi, lo = out[0].view(torch.float16).float(), out[1].view(torch.float16).float()
     assert torch.isfinite(hi).all() and torch.isfinite(lo).all() and hi.abs().max().item() == 65504.0
-    val = hi + lo
     big = o32.abs() > 65504
-    assert big.any() and ((val - o32).abs()[big] / o32.abs()[big]).max().item() < 2 ** -8
-    assert ((val - o32).abs()[~big] / o32.abs()[~big].clamp_min(1e-3)).max().item() < 1e-5
+    assert big.any()
+    val = hi + (lo - hi / 8) / 8
+    assert ((val - o32).abs()[~big] / o32.abs()[~big].clamp_min(1e-3)).max().item() < 2 ** -16
+    ref = ops.split_f16_comp(o32)  # (the torch statement of the same form)
+    assert torch.equal(ref[0], out[0]) and torch.equal(ref[1], out[1])
+    # the V form: identity GEMM of a matrix with outliers, columns >= 64 written fp16-hi / bf16-lo
+    K = N = 128
+    a = torch.randn(M, K, generator=g)
+    a[:, 70] *= 1.0e5
+    ap, wp = ops.split_bf16(a.to(dev), 3), ops.split_bf16(torch.eye(N).to(dev), 3)
+    op = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+    args = lib.GemmArgs(lib.ptr(ap[0]), lib.ptr(ap[1]), lib.ptr(wp[0]), lib.ptr(wp[1]), None, None, None, lib.ptr(op[0]), lib.ptr(op[1]), M, N, K, K, K, N, N, N,
+                        lib.ACT_NONE, lib.PREC_BF16X3, 0, 0, 0, 0)
+    args.out_f16_col0 = 64
+    lib.check(lib.load().mvp_gemm_bias_act_res(C.byref(args), lib.stream_ptr()), "gemm")
+    torch.cuda.synchronize()
+    hi, lo = op[0][:, 64:].view(torch.float16).float(), op[1][:, 64:].float()
+    av = a[:, 64:].to(dev)
+    big = av.abs() > 65504
+    assert big.any() and torch.isfinite(hi).all() and torch.isfinite(lo).all() and hi.abs().max().item() == 65504.0
+    assert ((hi + lo - av).abs()[big] / av.abs()[big]).max().item() < 2 ** -8
+    assert ((hi + lo - av).abs()[~big] / av.abs()[~big].clamp_min(1e-3)).max().item() < 1e-5
 
 
 def test_layernorm_and_attention_interleaved_outputs_match_separate(dev):
