@@ -44,7 +44,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 // hi saturates at the largest finite fp16 (one v_med3 per value): an activation outlier beyond 65504 then keeps hi finite and leaves its excess
 // to lo, which has fp32's exponent range (hi + lo still carries the value to bf16's 8 bits) instead of turning the whole GEMM row into NaN.
 __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), (_Float16)__builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
+  const f16x2_t h = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
   hi = __builtin_bit_cast(uint32_t, h);
   const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
   lo = __builtin_bit_cast(uint32_t, l);
@@ -54,11 +54,11 @@ __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, 
 // rounding.  Against the weight pair (fp16((1 - 2^-6) w), fp16((w + 64 d) / 8)), d = (1 - 2^-6) w - hi_w, the two fp16 products sum to
 // v * w + (v - hi) * 64 d: relative error ~2^-18 per term instead of the 2^-12 of a single fp16 rounding of w.
 __device__ __forceinline__ void split2_f16_comp(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), (_Float16)__builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
+  const f16x2_t h = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
   hi = __builtin_bit_cast(uint32_t, h);
-  const float ha = (float)h[0], hb = (float)h[1];
-  const float la = __builtin_fmaf(a - ha, 8.f, ha * 0.125f), lb = __builtin_fmaf(b - hb, 8.f, hb * 0.125f);
-  const f16x2_t l = {(_Float16)__builtin_fminf(__builtin_fmaxf(la, -65504.f), 65504.f), (_Float16)__builtin_fminf(__builtin_fmaxf(lb, -65504.f), 65504.f)};
+  // 8 (v - hi) + hi / 8 = 8 v - 7.875 hi: one multiply (exact) and one fma whose exact result fits fp32 — same bits as the long form
+  const float la = __builtin_fmaf((float)h[0], -7.875f, a * 8.f), lb = __builtin_fmaf((float)h[1], -7.875f, b * 8.f);
+  const f16x2_t l = {(_Float16)__builtin_amdgcn_fmed3f(la, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(lb, -65504.f, 65504.f)};
   lo = __builtin_bit_cast(uint32_t, l);
 }
 // Bit pattern <-> float through a SCALAR.  (ROCm 7.2's clang miscompiles __builtin_bit_cast(float, vec[e]) written directly on an
