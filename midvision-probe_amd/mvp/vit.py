@@ -128,6 +128,7 @@ class ViTEngine:
             self.precision = PREC_BF16X3
         self.heads, self.patch, self.ln_eps = heads, patch, ln_eps
         self.att_v_f16 = self.precision == lib.PREC_BF16X3 and os.environ.get("MVP_ATT_V", "f16") != "pair"
+        self.check_f16_range = os.environ.get("MVP_CHECK_F16_RANGE", "0") == "1"  # diagnostic: see _check_f16_range
         self.pos_embed_mode = pos_embed_mode
         sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
         self.C = sd["cls_token"].shape[-1]
@@ -274,12 +275,22 @@ class ViTEngine:
         ops.cls_rows(self.cls, pos, ws["x"], B, N, C)
         return ws, B, gh, gw
 
+    def _check_f16_range(self, what: str, pair, rows: int) -> None:
+        """MVP_CHECK_F16_RANGE=1 (diagnostic, synchronises): an fp16 half at +-65504 means an activation left the range of the two-product
+        mode (its pairs saturate instead of overflowing, so the result would be wrong without a NaN to show for it)."""
+        for t in ([pair.t[:rows]] if isinstance(pair, ops.IlvPair) else [pair[0][:rows], pair[1][:rows]]):
+            if not bool((t.view(torch.float16).abs() < 65504.0).all()):  # (NaN fails the comparison too)
+                raise lib.MvpError(f"f16x2: {what} holds values beyond fp16's range (|v| >= 65504): run this model with precision='bf16x3' (MVP_PRECISION=bf16x3)")
+
     def run_block(self, i: int, ws: dict, B: int, N: int) -> None:
         blk, C, M, pr = self.blocks[i], self.C, B * N, self.precision
         f2 = self.f16x2
+        chk = f2 and self.check_f16_range
         gp = lib.PREC_F16X2 if f2 else pr  # precision of the four block GEMMs
         x = ws["x"]
         ops.layernorm(x, blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps, out_f16=f2)
+        if chk:
+            self._check_f16_range(f"block {i}: LayerNorm 1 output", ws["xn"], M)
         # bf16x3: the V third of qkv leaves the GEMM as hi = fp16, lo = bf16, and the attention kernel holds its probabilities as one
         # fp16 value (csrc/attention.hip, VF16; MVP_ATT_V=pair brings back the bf16-pair probabilities of rounds 1-3)
         vf16 = self.att_v_f16
@@ -287,10 +298,16 @@ class ViTEngine:
         ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=gp, w_ilv=blk.get("qkv_w_ilv"),
                  f16_col0=2 * C if vf16 else 0)
         ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16, out_f16=f2)
+        if chk:
+            self._check_f16_range(f"block {i}: attention output", ws["ao"], M)
         ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=gp, w_ilv=blk.get("proj_w_ilv"))
         ops.layernorm(x, blk["n2w"], blk["n2b"], ws["xn"], M, C, self.ln_eps, out_f16=f2)
+        if chk:
+            self._check_f16_range(f"block {i}: LayerNorm 2 output", ws["xn"], M)
         ops.gemm(ws["xn"], blk["fc1_w"], M, self.hidden, C, bias=blk["fc1_b"], out=ws["hmid"], act=lib.ACT_GELU, precision=gp, w_ilv=blk.get("fc1_w_ilv"),
                  f16_col0=-1 if f2 else 0)
+        if chk:
+            self._check_f16_range(f"block {i}: GELU(fc1) output", ws["hmid"], M)
         ops.gemm(ws["hmid"], blk["fc2_w"], M, C, self.hidden, bias=blk["fc2_b"], residual=x, out_f32=x, precision=gp, w_ilv=blk.get("fc2_w_ilv"))
 
     def forward_taps(self, images: torch.Tensor, layers: Sequence[int], *, bn: Optional[Sequence[dict]] = None,
