@@ -38,6 +38,9 @@
 // maximum rises by more than 2^6 above it (always at a pair's first tile): probabilities stay below 2^6 = 64, far inside fp16.
 #include "mvp_common.h"
 
+#ifndef MVP_ATT_NT
+#define MVP_ATT_NT 0
+#endif
 namespace {
 
 // Diagnostic knobs (tools/attn_bench.py builds variants): MVP_ATT_PRIO 1 = s_setprio 1 around the two MFMA clusters of a tile (a wave in
@@ -278,11 +281,11 @@ __device__ __forceinline__ void attn_store(AttnState<SPLIT>& st, const mvp_atten
       }
       if (ilv) {
         const size_t o = ob + (dt >> 1) * 64 + (dt & 1) * 16;
-        *(u32x2_t*)(p.out_hi + o) = u32x2_t{h01, h23};
-        *(u32x2_t*)(p.out_hi + o + 32) = u32x2_t{l01, l23};
+        store_out((u32x2_t*)(p.out_hi + o), u32x2_t{h01, h23}, MVP_ATT_NT);
+        store_out((u32x2_t*)(p.out_hi + o + 32), u32x2_t{l01, l23}, MVP_ATT_NT);
       } else {
-        *(u32x2_t*)(p.out_hi + ob + dt * 16) = u32x2_t{h01, h23};
-        if (p.out_lo) *(u32x2_t*)(p.out_lo + ob + dt * 16) = u32x2_t{l01, l23};
+        store_out((u32x2_t*)(p.out_hi + ob + dt * 16), u32x2_t{h01, h23}, MVP_ATT_NT);
+        if (p.out_lo) store_out((u32x2_t*)(p.out_lo + ob + dt * 16), u32x2_t{l01, l23}, MVP_ATT_NT);
       }
     }
   }

@@ -4,6 +4,15 @@
 #pragma once
 #include "mvp_common.h"
 
+// MVP_EPI_AUX (diagnostic builds): cache-policy bits of the wide epilogue's output stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  Measured on the
+// four block GEMMs at M = 21 670 (profiles/r04_store_policy.txt); the shipped value is the default policy.
+#ifndef MVP_EPI_AUX
+#define MVP_EPI_AUX 0
+#endif
+#ifndef MVP_EPI_AUX_PAIR  // the same for the wide epilogue's pair-only forms (qkv, fc1: written once, read by the next kernel, nothing read back here)
+#define MVP_EPI_AUX_PAIR 18  // nt sc1: +1.8 % on the headline against the default policy, alternating on one box (profiles/r04_store_policy.txt)
+#endif
+
 namespace {
 
 // Branch-free erf GELU: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one
@@ -372,8 +381,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       if (F32OUT) {
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][0]), f2u(v[it][1]), f2u(v[it][2]), f2u(v[it][3])}, r_o32, ro[it].out, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][4]), f2u(v[it][5]), f2u(v[it][6]), f2u(v[it][7])}, r_o32, ro[it].out, 16, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][0]), f2u(v[it][1]), f2u(v[it][2]), f2u(v[it][3])}, r_o32, ro[it].out, 0, MVP_EPI_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][4]), f2u(v[it][5]), f2u(v[it][6]), f2u(v[it][7])}, r_o32, ro[it].out, 16, MVP_EPI_AUX);
       }
       if (PAIR) {
         uint32_t hw[4], lw[4];
@@ -387,8 +396,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].out, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].out, lo_soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].out, 0, (!RES && !F32OUT) ? MVP_EPI_AUX_PAIR : MVP_EPI_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].out, lo_soff, (!RES && !F32OUT) ? MVP_EPI_AUX_PAIR : MVP_EPI_AUX);
       }
     }
   }

@@ -3,6 +3,9 @@
 // bf16 pair that feeds the next MFMA GEMM.  HBM-bound: reads 4 B/elem, writes 2-4 B/elem.
 #include "mvp_common.h"
 
+#ifndef MVP_LN_NT
+#define MVP_LN_NT 0
+#endif
 namespace {
 
 constexpr int LN_MAXV = 4;  // 8-element chunks per lane: C <= 64 * 8 * 4 = 2048
@@ -64,11 +67,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
       }
       if (p.out_layout == MVP_PAIR_A_ILV32) {  // one array, hi | lo interleaved per 32 columns (an 8-element chunk never straddles a block)
         const size_t oi = (size_t)row * 2 * p.C + ilv32_col(c * 8);
-        *(u32x4_t*)(p.out_hi + oi) = u32x4_t{h[0], h[1], h[2], h[3]};
-        *(u32x4_t*)(p.out_hi + oi + 32) = u32x4_t{l[0], l[1], l[2], l[3]};
+        store_out((u32x4_t*)(p.out_hi + oi), u32x4_t{h[0], h[1], h[2], h[3]}, MVP_LN_NT);
+        store_out((u32x4_t*)(p.out_hi + oi + 32), u32x4_t{l[0], l[1], l[2], l[3]}, MVP_LN_NT);
       } else {
-        *(u32x4_t*)(p.out_hi + o) = u32x4_t{h[0], h[1], h[2], h[3]};
-        if (p.out_lo) *(u32x4_t*)(p.out_lo + o) = u32x4_t{l[0], l[1], l[2], l[3]};
+        store_out((u32x4_t*)(p.out_hi + o), u32x4_t{h[0], h[1], h[2], h[3]}, MVP_LN_NT);
+        if (p.out_lo) store_out((u32x4_t*)(p.out_lo + o), u32x4_t{l[0], l[1], l[2], l[3]}, MVP_LN_NT);
       }
       if (p.out_f32) {
         *(float4*)(p.out_f32 + o) = make_float4(y[0], y[1], y[2], y[3]);

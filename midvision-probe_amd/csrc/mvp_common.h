@@ -61,6 +61,13 @@ __device__ __forceinline__ void split2_f16_comp(float a, float b, uint32_t& hi, 
   const f16x2_t l = {(_Float16)__builtin_amdgcn_fmed3f(la, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(lb, -65504.f, 65504.f)};
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// Output stores of data that this kernel never reads back and the NEXT kernel reads once (operand pairs): MVP_OUT_NT 1 marks them non-temporal
+// (global_store ... nt), so they do not push the operands of the running kernel out of L2.  Per kernel: MVP_LN_NT, MVP_ATT_NT (A/B builds).
+template <class T>
+__device__ __forceinline__ void store_out(T* ptr, const T& v, const bool nt) {
+  if (nt) __builtin_nontemporal_store(v, ptr);
+  else *ptr = v;
+}
 // Bit pattern <-> float through a SCALAR.  (ROCm 7.2's clang miscompiles __builtin_bit_cast(float, vec[e]) written directly on an
 // element of an ext_vector: every e yields element 0 — the optimiser then narrows a 16-byte load to its first dword.  Passing the
 // element by value makes it a scalar first.)

@@ -203,6 +203,10 @@ def main():
     if "--prio" in sys.argv:  # priority forms of the main loop (MVP_PP_PRIO): static priority for waves 4-7 / no priority instructions
         extra["static_prio"] = build_ablate(1, "MVP_PP_PRIO", "prio")
         extra["no_prio"] = build_ablate(2, "MVP_PP_PRIO", "prio")
+    if "--store-policy" in sys.argv:  # cache policy of the wide epilogue's output stores (MVP_EPI_AUX): nt, sc0 sc1, nt sc1
+        extra["stores_nt"] = build_ablate(2, "MVP_EPI_AUX", "aux")
+        extra["stores_sc0_sc1"] = build_ablate(17, "MVP_EPI_AUX", "aux")
+        extra["stores_nt_sc1"] = build_ablate(18, "MVP_EPI_AUX", "aux")
     if "--persist-ab" in sys.argv:  # the tile loop of round 4: one tile per workgroup (no loop) / the loop without the prefetch ahead of the epilogue
         extra["one_tile_per_wg"] = build_ablate(1, "MVP_PP_NOLOOP", "noloop")
         extra["loop_cold_prologue"] = build_ablate(0, "MVP_PP_PREFETCH", "prefetch")
