@@ -41,6 +41,9 @@
 #ifndef MVP_ATT_NT
 #define MVP_ATT_NT 0
 #endif
+#ifndef MVP_ATT_LD_AUX  // cache policy of the K / V LDS-DMA loads (2 = nt): A/B builds, profiles/r04_store_policy.txt
+#define MVP_ATT_LD_AUX 0
+#endif
 namespace {
 
 // Diagnostic knobs (tools/attn_bench.py builds variants): MVP_ATT_PRIO 1 = s_setprio 1 around the two MFMA clusters of a tile (a wave in
@@ -301,11 +304,11 @@ __device__ __forceinline__ void attn_stage_piece(const mvp_attention_args& p, si
   if (MVP_ATT_ABLATE == 4) return;
   const int krow = min(key0 + r + rsub, p.N - 1);
   const size_t ro = (rowbase + krow) * p.ld_qkv + h * 64;
-  __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_hi + ro + HD + kc), LDS_PTR(kdst + r * 128), 16, 0, 0);
-  __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_hi + ro + 2 * HD + vc), LDS_PTR(vdst + r * 128), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_hi + ro + HD + kc), LDS_PTR(kdst + r * 128), 16, 0, MVP_ATT_LD_AUX);
+  __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_hi + ro + 2 * HD + vc), LDS_PTR(vdst + r * 128), 16, 0, MVP_ATT_LD_AUX);
   if (SPLIT == 3) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_lo + ro + HD + kc), LDS_PTR(kdst + TILE + r * 128), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_lo + ro + 2 * HD + vc), LDS_PTR(vdst + TILE + r * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_lo + ro + HD + kc), LDS_PTR(kdst + TILE + r * 128), 16, 0, MVP_ATT_LD_AUX);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(p.qkv_lo + ro + 2 * HD + vc), LDS_PTR(vdst + TILE + r * 128), 16, 0, MVP_ATT_LD_AUX);
   }
 }
 

@@ -9,6 +9,9 @@
 #ifndef MVP_EPI_AUX
 #define MVP_EPI_AUX 0
 #endif
+#ifndef MVP_EPI_LD_AUX  // the wide epilogue's fp32 residual loads (proj, fc2: x read for the last time before it is overwritten)
+#define MVP_EPI_LD_AUX 0
+#endif
 #ifndef MVP_EPI_AUX_PAIR  // the same for the wide epilogue's pair-only forms (qkv, fc1: written once, read by the next kernel, nothing read back here)
 #define MVP_EPI_AUX_PAIR 18  // nt sc1: +1.8 % on the headline against the default policy, alternating on one box (profiles/r04_store_policy.txt)
 #endif
@@ -335,8 +338,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
       ro_next[it] = offsets(m0 + wm0 + u * 16 + it * 8 + er);
       if (GATE) gpre[it] = __builtin_amdgcn_raw_buffer_load_b64(r_gate, ro_next[it].gate, 0, 0);
       if (RES) {
-        rpre[it][0] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 0, 0);
-        rpre[it][1] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 16, 0);
+        rpre[it][0] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 0, MVP_EPI_LD_AUX);
+        rpre[it][1] = __builtin_amdgcn_raw_buffer_load_b128(r_res, ro_next[it].res, 16, MVP_EPI_LD_AUX);
       }
     }
   };

@@ -6,6 +6,9 @@
 #ifndef MVP_LN_NT
 #define MVP_LN_NT 0
 #endif
+#ifndef MVP_LN_LD_NT  // the x loads non-temporal (A/B builds)
+#define MVP_LN_LD_NT 0
+#endif
 namespace {
 
 constexpr int LN_MAXV = 4;  // 8-element chunks per lane: C <= 64 * 8 * 4 = 2048
@@ -24,8 +27,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
+#if MVP_LN_LD_NT
+      typedef __attribute__((ext_vector_type(4))) float f4v;
+      const f4v t0 = __builtin_nontemporal_load((const f4v*)&xr[c * 2]), t1 = __builtin_nontemporal_load((const f4v*)&xr[c * 2 + 1]);
+      v[i][0] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+      v[i][1] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+#else
       v[i][0] = xr[c * 2];
       v[i][1] = xr[c * 2 + 1];
+#endif
       s += ((v[i][0].x + v[i][0].y) + (v[i][0].z + v[i][0].w)) + ((v[i][1].x + v[i][1].y) + (v[i][1].z + v[i][1].w));
     }
   }
