@@ -4,16 +4,25 @@
 #pragma once
 #include "mvp_common.h"
 
-// MVP_EPI_AUX (diagnostic builds): cache-policy bits of the wide epilogue's output stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  Measured on the
-// four block GEMMs at M = 21 670 (profiles/r04_store_policy.txt); the shipped value is the default policy.
-#ifndef MVP_EPI_AUX
+// Cache policy of the wide epilogue's output stores (gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1; profiles/r04_store_policy.txt).
+//   MVP_EPI_AUX_PAIR  the pair-only forms (qkv, fc1: written once, read by the NEXT kernel, nothing read back here).  Shipped: 18 = nt sc1 —
+//                     the stores no longer push the running launch's weight panels and A rows out of L2: +1.8 % / +3.1 % on the headline
+//                     (whole-library A/B builds alternating on one box, two boxes).
+//   MVP_EPI_AUX       every other output store (the residual forms: x is read again by LayerNorm and by the next residual add).  Shipped: 0 —
+//                     nt costs proj / fc2 3-6 %.  Defining it on the command line (tools/pp_bench.py --store-policy) sets the pair forms too.
+//   MVP_EPI_LD_AUX    the fp32 residual loads.  Shipped: 0 (nt: -1.6 % on the headline).
+#ifdef MVP_EPI_AUX
+#ifndef MVP_EPI_AUX_PAIR
+#define MVP_EPI_AUX_PAIR MVP_EPI_AUX
+#endif
+#else
 #define MVP_EPI_AUX 0
+#ifndef MVP_EPI_AUX_PAIR
+#define MVP_EPI_AUX_PAIR 18
 #endif
-#ifndef MVP_EPI_LD_AUX  // the wide epilogue's fp32 residual loads (proj, fc2: x read for the last time before it is overwritten)
+#endif
+#ifndef MVP_EPI_LD_AUX
 #define MVP_EPI_LD_AUX 0
-#endif
-#ifndef MVP_EPI_AUX_PAIR  // the same for the wide epilogue's pair-only forms (qkv, fc1: written once, read by the next kernel, nothing read back here)
-#define MVP_EPI_AUX_PAIR 18  // nt sc1: +1.8 % on the headline against the default policy, alternating on one box (profiles/r04_store_policy.txt)
 #endif
 
 namespace {

@@ -204,6 +204,7 @@ def main():
         extra["static_prio"] = build_ablate(1, "MVP_PP_PRIO", "prio")
         extra["no_prio"] = build_ablate(2, "MVP_PP_PRIO", "prio")
     if "--store-policy" in sys.argv:  # cache policy of the wide epilogue's output stores (MVP_EPI_AUX): nt, sc0 sc1, nt sc1
+        extra["stores_default"] = build_ablate(0, "MVP_EPI_AUX", "aux")  # (the shipped build: pair-only forms nt sc1, the rest default)
         extra["stores_nt"] = build_ablate(2, "MVP_EPI_AUX", "aux")
         extra["stores_sc0_sc1"] = build_ablate(17, "MVP_EPI_AUX", "aux")
         extra["stores_nt_sc1"] = build_ablate(18, "MVP_EPI_AUX", "aux")
