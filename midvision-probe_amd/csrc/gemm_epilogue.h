@@ -24,6 +24,9 @@
 #ifndef MVP_EPI_LD_AUX
 #define MVP_EPI_LD_AUX 0
 #endif
+#ifndef MVP_EPI_UNI_NT  // 1: gemm_epilogue_uni's pair-only outputs (conv + ReLU -> pair: ResNet / DPT layers, the tile kernels' qkv / fc1) nt sc1 too (A/B builds)
+#define MVP_EPI_UNI_NT 0
+#endif
 
 namespace {
 
@@ -472,6 +475,7 @@ __device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[
   const __amdgpu_buffer_rsrc_t r_olo = rsrc(oilv ? (const void*)p.out_hi : (const void*)p.out_lo);  // interleaved: the lo half sits 64 bytes behind the hi half
   const int lo_soff = oilv ? 64 : 0;
   const bool has_pair = p.out_hi != nullptr;
+  const bool nt_pair = has_pair && p.out_f32 == nullptr && p.residual == nullptr && x_rhi == nullptr;  // pair-only form (MVP_EPI_UNI_NT builds)
   const bool f16_cols = has_pair && p.out_f16_col0 != 0 && (n0 + wn0) >= p.out_f16_col0;  // (wave-uniform: out_f16_col0 % 64 == 0 or -1)
   const int ob = col_ok ? ncol * 4 : SENT;
   const u32x4_t bias_a = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 0, 0), bias_b = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 16, 0);
@@ -591,8 +595,13 @@ __device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[
           for (int e = 0; e < 4; ++e) split2_bf16(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
         }
       }
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].opair, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].opair, lo_soff, 0);
+      if (MVP_EPI_UNI_NT && nt_pair) {  // (wave-uniform; stores only: both paths leave the same counts behind)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].opair, 0, 18);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].opair, lo_soff, 18);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{hw[0], hw[1], hw[2], hw[3]}, r_ohi, ro[it].opair, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{lw[0], lw[1], lw[2], lw[3]}, r_olo, ro[it].opair, lo_soff, 0);
+      }
       if (EXT) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{mbits[it][0], mbits[it][1]}, r_omask, ro[it].mask, 0, 0);
     }
   }
