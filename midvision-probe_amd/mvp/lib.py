@@ -312,7 +312,15 @@ def check(code: int, what: str) -> None:
         raise MvpError(f"{what} failed: {load().mvp_strerror(code).decode()} (code {code})")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> int:
+    """Handle of the calling thread's current HIP stream on the current device.  Every launch asks for it: the raw accessors cost
+    ~0.3 us against ~8 us for torch.cuda.current_stream().cuda_stream (a tenth of a probe step's host time, tools/micro/host_profile.py)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
