@@ -213,7 +213,7 @@ def main():
         extra["loop_cold_prologue"] = build_ablate(0, "MVP_PP_PREFETCH", "prefetch")
         extra["loop_strict_first_wait"] = build_ablate(0, "MVP_PP_RELAXED", "relaxed")
         r03 = os.path.join(REPO, "tools", "micro", "libpp_r03.so")  # round 3's kernel (git show 6fdc23d:.../gemm_pp.hip + gemm_epilogue.h), built in the build container
-        if os.path.exists(r03):
+        if os.path.exists(r03) and PREC == 3:  # (round 3's kernel has no two-product mode)
             l3 = C.CDLL(r03)
             l3.mvp_gemm_pp.argtypes = [C.POINTER(lib.GemmArgs), C.c_void_p]
             l3.mvp_gemm_pp.restype = C.c_int
