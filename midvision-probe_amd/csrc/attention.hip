@@ -314,6 +314,7 @@ __device__ __forceinline__ void attn_stage_piece(const mvp_attention_args& p, si
 
 template <int SPLIT, bool VF16 = false>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attention_args p) {
+  f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int STAGE = 2 * NARR * TILE;  // K (hi[,lo]) then V (hi[,lo])
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attenti
 // issue next pair's tile 0 + Q -> tiles 1.. -> vmcnt(0) (the prefetch, issued long before) -> output stores -> barrier.
 template <int SPLIT, bool VF16 = false>
 __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_attention_args p) {
+  f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int STAGE = 2 * NARR * TILE;

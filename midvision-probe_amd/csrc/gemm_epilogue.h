@@ -30,25 +30,26 @@
 
 namespace {
 
-// Branch-free erf GELU: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7), one v_exp + one
-// v_rcp.  (ocml erff measured ~17 us of VALU on the fc1 epilogue.)
+// Branch-free erf GELU: Abramowitz-Stegun 7.1.26 for 1 - erf (|erf error| <= 1.5e-7), one v_exp + one v_rcp.  (ocml erff measured
+// ~17 us of VALU on the fc1 epilogue.)  Round 4 (the fc1 epilogue is bound by its vector instructions — 26 per value with the operand
+// pair — and the two-product kernel is cycle-bound): 13 instructions per value instead of 15, from
+//     GELU(x) = x/2 (1 + erf(|x|/sqrt2) sign x) = max(x, 0) - |x| (1 - erf(a)) / 2,   a = |x| / sqrt2,   1 - erf(a) = poly(t) exp(-a^2),  t = 1 / (1 + p a)
+// with b = a sqrt(log2 e): exp(-a^2) = exp2(-b b) (raw v_exp_f32: results below 2^-126 are zero either way), p a = (p / sqrt(log2 e)) b, the 1/2
+// folded into the polynomial's coefficients; no copysign, no x/2.  Max |error| against fp64 over [-12, 12]: 3.3e-7 (the previous form: 4.7e-7).
 // Every multiply-add is spelled out and contraction is off: the function is inlined into several epilogues (gemm_epilogue,
-// gemm_epilogue_wide) whose surrounding code would otherwise let the compiler fuse differently per call site — and a batch must get
-// the same bits whichever GEMM kernel its forward happens to use (grouped forwards use the large-M kernel, single batches the tiles).
+// gemm_epilogue_wide, gemm_epilogue_uni) whose surrounding code would otherwise let the compiler fuse differently per call site — and a batch must
+// get the same bits whichever GEMM kernel its forward happens to use (grouped forwards use the large-M kernel, single batches the tiles).
 __device__ __forceinline__ float gelu_erf(float x) {
 #pragma clang fp contract(off)
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-  poly = __builtin_fmaf(t, poly, 1.421413741f);
-  poly = __builtin_fmaf(t, poly, -0.284496736f);
-  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  const float b = fabsf(x) * 0.8493218002880191f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2727374808792225f, b, 1.0f));
+  float poly = __builtin_fmaf(t, 0.5307027145f, -0.7265760135f);
+  poly = __builtin_fmaf(t, poly, 0.7107068705f);
+  poly = __builtin_fmaf(t, poly, -0.142248368f);
+  poly = __builtin_fmaf(t, poly, 0.127414796f);
   poly = t * poly;
-  const float e = __expf(-(ax * ax));
-  const float erf_abs = __builtin_fmaf(-poly, e, 1.0f);
-  const float erfv = copysignf(erf_abs, x);
-  const float hx = 0.5f * x;
-  return __builtin_fmaf(hx, erfv, hx);
+  const float pe = poly * __builtin_amdgcn_exp2f(-(b * b));
+  return __builtin_fmaf(-fabsf(x), pe, fmaxf(x, 0.f));
 }
 
 // Logical tile index -> (tm, tn), XCD-region-major.  xcd_remap() hands each XCD one contiguous slice of the logical
@@ -90,6 +91,7 @@ __device__ __forceinline__ void region_tile(int L, int TM, int TN, int M, int N,
 template <int NT, int MT, int WN, bool EXT, class ARGS>
 __device__ __forceinline__ void gemm_epilogue(const ARGS& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
                                               const int m0, const int n0, const int wm0, const int wn0) {
+  f16_saturate_mode();  // (the pair outputs' fp16 forms saturate instead of overflowing: mvp_common.h)
   const int frow = lane & 15;
   const int fq = lane >> 4;
   // EXT = false compiles the ReLU-gate / second-residual / post-residual-ReLU features out of the
@@ -298,6 +300,7 @@ struct gemm_epilogue_wide_ops {
 template <int NT, int MT, int WN, int ACT, bool RES, bool F32OUT, bool PAIR, bool GATE = false, class ARGS = mvp_gemm_args, class HOOK>
 __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
                                                    const int m0, const int n0, const int wm0, const int wn0, HOOK&& after_first_loads) {
+  f16_saturate_mode();  // (the pair outputs' fp16 forms saturate instead of overflowing: mvp_common.h)
   static_assert(WN == 64 && NT == 4 && MT == 8, "wave tile 128 x 64");
   static_assert(F32OUT != PAIR, "one output form per instantiation (4 stores per unit)");
   constexpr int EPW = WN + 4;                 // padded scratch row, floats
@@ -450,6 +453,7 @@ __host__ __device__ __forceinline__ bool gemm_epilogue_uni_ok(const mvp_gemm_arg
 template <int NT, int MT, int WN, bool EXT, class ARGS = mvp_gemm_args, class HOOK>
 __device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[NT][MT], char* smem, const int wave, const int lane,
                                                   const int m0, const int n0, const int wm0, const int wn0, HOOK&& after_first_loads) {
+  f16_saturate_mode();  // (the pair outputs' fp16 forms saturate instead of overflowing: mvp_common.h)
   static_assert((WN == 64 || WN == 32) && NT == WN / 16, "wave tile 16k x 64 or 16k x 32");
   constexpr int EPW = WN + 4;                 // padded scratch row, floats
   constexpr int EP_BYTES = 16 * EPW * 4;      // per wave

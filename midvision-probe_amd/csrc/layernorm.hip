@@ -16,6 +16,7 @@ constexpr int LN_MAXV = 4;  // 8-element chunks per lane: C <= 64 * 8 * 4 = 2048
 // Each lane owns chunks of 8 consecutive elements (two float4 loads, ONE 16-byte store per output array: 8-byte
 // stores run at 0.5-0.7x the 16-byte rate on gfx950).
 __global__ __launch_bounds__(256) void layernorm_kernel(const mvp_layernorm_args p) {
+  f16_saturate_mode();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.M) return;

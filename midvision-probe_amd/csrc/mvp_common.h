@@ -39,12 +39,30 @@ __device__ __forceinline__ void split2_bf16(float a, float b, uint32_t& hi, uint
   const bf16x2_t l = {(__bf16)(a - ha), (__bf16)(b - hb)};
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// Saturation of the fp16 halves.  MVP_F16_OVFL 1 (shipped): the kernels that write fp16 halves set MODE.FP16_OVFL once (f16_saturate_mode():
+// an overflowing fp16 conversion then returns +-65504 instead of inf; inf only from inf) and the conversions need no clamp — 4 v_med3 fewer per
+// two values in the fc1 epilogue, which is bound by its vector instructions.  0: explicit v_med3 clamps (the first form; same results).
+#ifndef MVP_F16_OVFL
+#define MVP_F16_OVFL 1
+#endif
+__device__ __forceinline__ void f16_saturate_mode() {
+#if MVP_F16_OVFL
+  __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);  // hwreg(HW_REG_MODE, offset 23, 1 bit) = FP16_OVFL
+#endif
+}
+__device__ __forceinline__ float f16_clamp(float v) {
+#if MVP_F16_OVFL
+  return v;
+#else
+  return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+#endif
+}
 // The mixed form of mvp_gemm_args.out_f16_col0: hi = fp16(v) (rne), lo = bf16(v - hi), two values packed like split2_bf16.
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 // hi saturates at the largest finite fp16 (one v_med3 per value): an activation outlier beyond 65504 then keeps hi finite and leaves its excess
 // to lo, which has fp32's exponent range (hi + lo still carries the value to bf16's 8 bits) instead of turning the whole GEMM row into NaN.
 __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  const f16x2_t h = {(_Float16)f16_clamp(a), (_Float16)f16_clamp(b)};
   hi = __builtin_bit_cast(uint32_t, h);
   const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
   lo = __builtin_bit_cast(uint32_t, l);
@@ -54,11 +72,11 @@ __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, 
 // rounding.  Against the weight pair (fp16((1 - 2^-6) w), fp16((w + 64 d) / 8)), d = (1 - 2^-6) w - hi_w, the two fp16 products sum to
 // v * w + (v - hi) * 64 d: relative error ~2^-18 per term instead of the 2^-12 of a single fp16 rounding of w.
 __device__ __forceinline__ void split2_f16_comp(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  const f16x2_t h = {(_Float16)f16_clamp(a), (_Float16)f16_clamp(b)};
   hi = __builtin_bit_cast(uint32_t, h);
   // 8 (v - hi) + hi / 8 = 8 v - 7.875 hi: one multiply (exact) and one fma whose exact result fits fp32 — same bits as the long form
   const float la = __builtin_fmaf((float)h[0], -7.875f, a * 8.f), lb = __builtin_fmaf((float)h[1], -7.875f, b * 8.f);
-  const f16x2_t l = {(_Float16)__builtin_amdgcn_fmed3f(la, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(lb, -65504.f, 65504.f)};
+  const f16x2_t l = {(_Float16)f16_clamp(la), (_Float16)f16_clamp(lb)};
   lo = __builtin_bit_cast(uint32_t, l);
 }
 // Output stores of data that this kernel never reads back and the NEXT kernel reads once (operand pairs): MVP_OUT_NT 1 marks them non-temporal
