@@ -59,10 +59,11 @@ __device__ __forceinline__ float f16_clamp(float v) {
 }
 // The mixed form of mvp_gemm_args.out_f16_col0: hi = fp16(v) (rne), lo = bf16(v - hi), two values packed like split2_bf16.
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
 // hi saturates at the largest finite fp16 (one v_med3 per value): an activation outlier beyond 65504 then keeps hi finite and leaves its excess
 // to lo, which has fp32's exponent range (hi + lo still carries the value to bf16's 8 bits) instead of turning the whole GEMM row into NaN.
 __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)f16_clamp(a), (_Float16)f16_clamp(b)};
+  const f16x2_t h = __builtin_convertvector(f32x2v_t{f16_clamp(a), f16_clamp(b)}, f16x2_t);  // one v_cvt_pk_f16_f32; the halves are read back by v_fma_mix
   hi = __builtin_bit_cast(uint32_t, h);
   const bf16x2_t l = {(__bf16)(a - (float)h[0]), (__bf16)(b - (float)h[1])};
   lo = __builtin_bit_cast(uint32_t, l);
@@ -72,11 +73,11 @@ __device__ __forceinline__ void split2_f16_bf16(float a, float b, uint32_t& hi, 
 // rounding.  Against the weight pair (fp16((1 - 2^-6) w), fp16((w + 64 d) / 8)), d = (1 - 2^-6) w - hi_w, the two fp16 products sum to
 // v * w + (v - hi) * 64 d: relative error ~2^-18 per term instead of the 2^-12 of a single fp16 rounding of w.
 __device__ __forceinline__ void split2_f16_comp(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const f16x2_t h = {(_Float16)f16_clamp(a), (_Float16)f16_clamp(b)};
+  const f16x2_t h = __builtin_convertvector(f32x2v_t{f16_clamp(a), f16_clamp(b)}, f16x2_t);
   hi = __builtin_bit_cast(uint32_t, h);
   // 8 (v - hi) + hi / 8 = 8 v - 7.875 hi: one multiply (exact) and one fma whose exact result fits fp32 — same bits as the long form
   const float la = __builtin_fmaf((float)h[0], -7.875f, a * 8.f), lb = __builtin_fmaf((float)h[1], -7.875f, b * 8.f);
-  const f16x2_t l = {(_Float16)f16_clamp(la), (_Float16)f16_clamp(lb)};
+  const f16x2_t l = __builtin_convertvector(f32x2v_t{f16_clamp(la), f16_clamp(lb)}, f16x2_t);
   lo = __builtin_bit_cast(uint32_t, l);
 }
 // Output stores of data that this kernel never reads back and the NEXT kernel reads once (operand pairs): MVP_OUT_NT 1 marks them non-temporal
