@@ -63,7 +63,8 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 6 /* 6: mvp_gemm_args.out_f16_col0, mvp_attention_args.v_format (both structs grew by one int at the end; zero = the ABI 5 behaviour)
+#define MVP_ABI_VERSION 7 /* 7: mvp_bn_running_update_n (a new export; every struct as in 6)
+                             6: mvp_gemm_args.out_f16_col0, mvp_attention_args.v_format (both structs grew by one int at the end; zero = the ABI 5 behaviour)
                              5: mvp_upconv3_fwd_gather, mvp_upconv3_grad_boxsum; mvp_gemm_pp accepts conv; depth-loss workspace grew (query mvp_depth_loss_workspace_bytes) */
 int mvp_get_info(mvp_info_t* out);
 const char* mvp_strerror(int code);
@@ -307,6 +308,11 @@ typedef struct {
   int C; float momentum;
 } mvp_bn_running_update_args;
 int mvp_bn_running_update(const mvp_bn_running_update_args*, void* stream);
+/* The same update for n (1..MVP_BN_RUNNING_MAX) BatchNorm modules in ONE launch — the four tap BNs of a multilayer extract
+ * (dino.py:185-191) are handed to the trainer together, and beside a frozen forward every launch of the probe step's stream costs
+ * its queueing delay, not its 2 us of work.  Element-wise identical to n calls of mvp_bn_running_update. */
+#define MVP_BN_RUNNING_MAX 8
+int mvp_bn_running_update_n(const mvp_bn_running_update_args* items, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * NCHW fp32 feature maps -> token-major bf16 pair (+ transposed copy).  Fallback packer

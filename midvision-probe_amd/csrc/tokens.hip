@@ -197,6 +197,16 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const mvp_bn_run
   p.running_var[c] = bn_running(p.running_var[c], p.stats[2 * p.C + c], p.momentum);
 }
 
+struct bn_running_update_set { mvp_bn_running_update_args item[MVP_BN_RUNNING_MAX]; };
+__global__ __launch_bounds__(256) void bn_running_update_n_kernel(const bn_running_update_set s) {
+  const mvp_bn_running_update_args& p = s.item[blockIdx.y];  // wave-uniform: scalar loads from the kernel-argument segment
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && p.num_batches_tracked) *p.num_batches_tracked += 1;
+  if (c >= p.C) return;
+  p.running_mean[c] = bn_running(p.running_mean[c], p.stats[c], p.momentum);
+  p.running_var[c] = bn_running(p.running_var[c], p.stats[2 * p.C + c], p.momentum);
+}
+
 // eval (running stats) / identity modes: scale & shift without a statistics pass.
 __global__ __launch_bounds__(256) void bn_prep_kernel(const mvp_bn_tokens_args p, float* __restrict__ ss) {
   const int c = blockIdx.x * 256 + threadIdx.x;
@@ -385,6 +395,24 @@ extern "C" int mvp_bn_tokens_to_nchw_fwd(const mvp_bn_tokens_args* a, void* stre
 extern "C" int mvp_bn_running_update(const mvp_bn_running_update_args* a, void* stream) {
   if (!a || !a->stats || !a->running_mean || !a->running_var || a->C <= 0) return MVP_EINVAL;
   hipLaunchKernelGGL(bn_running_update_kernel, dim3((a->C + 255) / 256), dim3(256), 0, (hipStream_t)stream, *a);
+  MVP_LAUNCH_CHECK();
+  return MVP_OK;
+}
+
+extern "C" int mvp_bn_running_update_n(const mvp_bn_running_update_args* items, int n, void* stream) {
+  if (!items || n <= 0 || n > MVP_BN_RUNNING_MAX) return MVP_EINVAL;
+  bn_running_update_set s;
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const mvp_bn_running_update_args& a = items[i];
+    if (!a.stats || !a.running_mean || !a.running_var || a.C <= 0) return MVP_EINVAL;
+    for (int j = 0; j < i; ++j)  // two items on one module would race (and the order of their updates matters)
+      if (items[j].running_mean == a.running_mean || items[j].running_var == a.running_var) return MVP_EINVAL;
+    s.item[i] = a;
+    cmax = a.C > cmax ? a.C : cmax;
+  }
+  for (int i = n; i < MVP_BN_RUNNING_MAX; ++i) s.item[i] = items[0];  // never indexed (grid.y = n)
+  hipLaunchKernelGGL(bn_running_update_n_kernel, dim3((cmax + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, s);
   MVP_LAUNCH_CHECK();
   return MVP_OK;
 }

@@ -173,6 +173,47 @@ def linear_head_k1(feats: Sequence[torch.Tensor], weight: torch.Tensor, bias: to
     return _LinearHeadK1.apply(weight, bias, pack, precision)
 
 
+def linear_bins_forward(weight, bias, pack: PackedFeatures, precision: int, min_depth: float, max_depth: float):
+    """The launches of ``_LinearBinsHead.forward`` (no tape): -> (depth [B,1,4h,4w], inv, gate).  Shared by the autograd Function and
+    by the tape-free probe step (mvp/fused_step.py), so both issue the same kernels with the same arguments."""
+    K, Ctot = weight.shape[0], pack.Ctot
+    dev = weight.device
+    w2 = weight.detach().reshape(K, Ctot).float()
+    if pack.Cpad != Ctot:
+        wpad = w2.new_zeros(K, pack.Cpad)
+        wpad[:, :Ctot] = w2
+        w2 = wpad
+    wp = ops.split_bf16(w2.contiguous(), precision)
+    l0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
+    ops.gemm(pack.tok, wp, pack.M, K, pack.Cpad, bias=bias.detach().float().contiguous(), out_f32=l0, precision=precision)
+    B, h, w = pack.B, pack.h, pack.w
+    P = B * 16 * h * w
+    depth = torch.empty(B, 1, 4 * h, 4 * w, dtype=torch.float32, device=dev)
+    inv = torch.empty(P, dtype=torch.float32, device=dev)
+    gate = torch.empty(P, K // 8, dtype=torch.uint8, device=dev)
+    a = lib.LinearBinsArgs(lib.ptr(l0), lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), None, None, B, h, w, K, 4, min_depth, max_depth)
+    lib.call("mvp_linear_bins_fwd", a)
+    return depth, inv, gate
+
+
+def linear_bins_backward(gd, depth, inv, gate, pack: PackedFeatures, precision: int, K: int, min_depth: float, max_depth: float,
+                         dw_dst: Optional[torch.Tensor], db_dst: Optional[torch.Tensor]):
+    """The launches of ``_LinearBinsHead.backward``: -> (dW [K, Ctot], db [K]); written into ``dw_dst`` / ``db_dst`` (the parameters'
+    slots of FlatAdamW's flat gradient) when given and the packing has no channel padding."""
+    B, h, w = pack.B, pack.h, pack.w
+    dev = gd.device
+    gl0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
+    a = lib.LinearBinsArgs(None, lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), lib.ptr(gd.contiguous().float()), lib.ptr(gl0), B, h, w, K, 4,
+                           min_depth, max_depth)
+    lib.call("mvp_linear_bins_bwd", a)
+    dW = _head_weight_grad(gl0, K, pack, precision, dst=dw_dst)
+    db = db_dst
+    if db is None:
+        db = torch.empty(K, dtype=torch.float32, device=dev)
+    ops.colsum(gl0, db, pack.M, K)
+    return dW, db
+
+
 class _LinearBinsHead(torch.autograd.Function):
     """DepthHead(linear, k=1, bindepth) in one piece (probes.py:153-157,176-200,427-432):
     GEMM at token resolution -> fused [bilinear x4 + bin expectation] kernel that keeps one gate
@@ -180,24 +221,8 @@ class _LinearBinsHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, bias, pack: PackedFeatures, precision: int, n_bins: int, min_depth: float, max_depth: float):
-        K, Ctot = weight.shape[0], pack.Ctot
-        dev = weight.device
-        w2 = weight.detach().reshape(K, Ctot).float()
-        if pack.Cpad != Ctot:
-            wpad = w2.new_zeros(K, pack.Cpad)
-            wpad[:, :Ctot] = w2
-            w2 = wpad
-        wp = ops.split_bf16(w2.contiguous(), precision)
-        l0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
-        ops.gemm(pack.tok, wp, pack.M, K, pack.Cpad, bias=bias.detach().float().contiguous(), out_f32=l0, precision=precision)
-        B, h, w = pack.B, pack.h, pack.w
-        P = B * 16 * h * w
-        depth = torch.empty(B, 1, 4 * h, 4 * w, dtype=torch.float32, device=dev)
-        inv = torch.empty(P, dtype=torch.float32, device=dev)
-        gate = torch.empty(P, K // 8, dtype=torch.uint8, device=dev)
-        a = lib.LinearBinsArgs(lib.ptr(l0), lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), None, None, B, h, w, K, 4, min_depth, max_depth)
-        lib.call("mvp_linear_bins_fwd", a)
-        ctx.pack, ctx.precision, ctx.cfg = pack, precision, (K, min_depth, max_depth)
+        depth, inv, gate = linear_bins_forward(weight, bias, pack, precision, min_depth, max_depth)
+        ctx.pack, ctx.precision, ctx.cfg = pack, precision, (weight.shape[0], min_depth, max_depth)
         ctx.wshape, ctx.generation = weight.shape, pack.generation
         ctx.params = (weight, bias)
         ctx.save_for_backward(depth, inv, gate)
@@ -208,20 +233,11 @@ class _LinearBinsHead(torch.autograd.Function):
         depth, inv, gate = ctx.saved_tensors
         pack, pr = ctx.pack, ctx.precision
         K, mn, mx = ctx.cfg
-        B, h, w, Ctot = pack.B, pack.h, pack.w, pack.Ctot
-        dev = gd.device
         if pack.generation != ctx.generation:
             raise lib.MvpError("linear head backward: the backbone ran again before this backward and overwrote the packed "
                                "features of this step (call backward before the next model(images))")
-        gl0 = torch.empty(pack.M, K, dtype=torch.float32, device=dev)
-        a = lib.LinearBinsArgs(None, lib.ptr(depth), lib.ptr(inv), lib.ptr(gate), lib.ptr(gd.contiguous().float()), lib.ptr(gl0), B, h, w, K, 4, mn, mx)
-        lib.call("mvp_linear_bins_bwd", a)
         wparam, bparam = ctx.params
-        dW = _head_weight_grad(gl0, K, pack, pr, dst=_grad_dst(wparam, (K, Ctot)))
-        db = _grad_dst(bparam, (K,))
-        if db is None:
-            db = torch.empty(K, dtype=torch.float32, device=dev)
-        ops.colsum(gl0, db, pack.M, K)
+        dW, db = linear_bins_backward(gd, depth, inv, gate, pack, pr, K, mn, mx, _grad_dst(wparam, (K, pack.Ctot)), _grad_dst(bparam, (K,)))
         return dW.reshape(ctx.wshape), db, None, None, None, None, None
 
 

@@ -22,6 +22,7 @@ PREC_F16X2 = 2  # two fp16 products per GEMM contraction over compensated fp16 p
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 RESIZE_NEAREST, RESIZE_BILINEAR, RESIZE_BICUBIC = 0, 1, 2
 PAIR_SEPARATE, PAIR_A_ILV32, PAIR_W_ILV32 = 0, 1, 2  # mvp_gemm_args.pair_layout (bit flags)
+BN_RUNNING_MAX = 8  # MVP_BN_RUNNING_MAX: modules per mvp_bn_running_update_n launch
 TILES_SHARED, TILES_NO_PP, TILES_NO_UNI = 1, 2, 4
 
 _vp = C.c_void_p
@@ -218,6 +219,7 @@ SYMBOLS = {
     "mvp_bn_tokens_workspace_bytes": None,
     "mvp_bn_tokens_to_nchw_fwd": BnTokensArgs,
     "mvp_bn_running_update": BnRunningUpdateArgs,
+    "mvp_bn_running_update_n": None,
     "mvp_pack_nchw_tokens": PackNchwArgs,
     "mvp_resize_fwd": ResizeArgs,
     "mvp_resize_bwd": ResizeArgs,
@@ -273,6 +275,8 @@ def load() -> C.CDLL:
         if st is not None:
             fn.argtypes = [C.POINTER(st), _vp]
             fn.restype = _i
+    lib.mvp_bn_running_update_n.argtypes = [C.POINTER(BnRunningUpdateArgs), _i, _vp]
+    lib.mvp_bn_running_update_n.restype = _i
     lib.mvp_get_info.argtypes = [C.POINTER(Info)]
     lib.mvp_get_info.restype = _i
     lib.mvp_strerror.argtypes = [_i]

@@ -354,6 +354,20 @@ def bn_running_update(stats, running_mean, running_var, num_batches_tracked, Cdi
                                                                lib.ptr(num_batches_tracked), Cdim, momentum))
 
 
+def bn_running_update_many(items, momentum=0.1) -> None:
+    """``bn_running_update`` for several BatchNorm modules — items of (stats, running_mean, running_var, num_batches_tracked, Cdim) — in
+    one launch per lib.BN_RUNNING_MAX of them (mvp_bn_running_update_n; element-wise the same bits)."""
+    if len({it[1].data_ptr() for it in items}) != len(items):  # one module tapped twice: its updates are ordered, one launch each
+        for st, rm, rv, nbt, Cdim in items:
+            bn_running_update(st, rm, rv, nbt, Cdim, momentum)
+        return
+    for i0 in range(0, len(items), lib.BN_RUNNING_MAX):
+        part = items[i0:i0 + lib.BN_RUNNING_MAX]
+        arr = (lib.BnRunningUpdateArgs * len(part))(*[
+            lib.BnRunningUpdateArgs(lib.ptr(st), lib.ptr(rm), lib.ptr(rv), lib.ptr(nbt), Cdim, momentum) for st, rm, rv, nbt, Cdim in part])
+        lib.check(lib.load().mvp_bn_running_update_n(arr, len(part), lib.stream_ptr()), "mvp_bn_running_update_n")
+
+
 def pack_nchw_tokens(nchw: torch.Tensor, B: int, Cdim: int, hw: int, *, tok: Optional[Pair] = None, ld_tok=0, col_off=0,
                      tokT: Optional[Pair] = None, ldT=0) -> None:
     t_hi, t_lo = tok if tok is not None else (None, None)

@@ -150,6 +150,18 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         self.finish_pending()
         self._gather_stray_grads()
+        return self._step_flat()
+
+    def step_in_place(self):
+        """``step()`` for a caller whose kernels have just written EVERY gradient into its slot of the flat buffer (the tape-free
+        probe step, mvp/fused_step.py): no walk over the parameters, and none of torch.optim.Optimizer's per-call wrappers (profiler
+        range, hook dispatch, the LR scheduler's call tracker) — that caller has checked that no step hook is registered.  Call under
+        ``torch.no_grad()``."""
+        self.finish_pending()
+        self._opt_called = True  # what the LR scheduler's wrapper of step() records (its first-call ordering warning reads it)
+        return self._step_flat()
+
+    def _step_flat(self):
         self._step += 1
         lr = float(self.param_groups[0]["lr"])
         from .dist import world_size as _world
@@ -167,6 +179,15 @@ class FlatAdamW(torch.optim.Optimizer):
         world = self.all_reduce_grads()
         self._apply(self.flat_grad, world, lr, self._step)
         return None
+
+    def grad_slots(self):
+        """[(parameter, its slot of the flat gradient as a view of the parameter's shape)], in flat-buffer order."""
+        out, off = [], 0
+        for p in self._params:
+            n = p.numel()
+            out.append((p, self.flat_grad[off:off + n].view(p.shape)))
+            off += (n + 3) // 4 * 4
+        return out
 
     def state_dict(self):
         self.finish_pending()

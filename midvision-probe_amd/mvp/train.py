@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import functional as MF
+from . import fused_step
 from .pipeline import freeze_gc, pipelined_features
 
 
@@ -48,6 +49,9 @@ def train_depth_step(model, probe, optimizer, scheduler, loss_fn, images, target
     if feats is None:
         feats = extract_features(model, images, detach_model)
     _finish_pending(optimizer)
+    plan = fused_step.plan_for(probe, optimizer, scheduler, loss_fn, feats, target, scale_invariant)
+    if plan is not None:  # the benchmarked probe: the same launches without the autograd tape (mvp/fused_step.py)
+        return plan.run(feats, target, scheduler)
     pred = probe(feats)
     pred = MF.interpolate(pred, size=target.shape[-2:], mode="bilinear")
     if scale_invariant:  # train_depth.py:116-118: per-image scale/shift fit (detached) + clamp, one fused kernel each way

@@ -398,6 +398,8 @@ class ViTEngine:
         if (G > 1 or span is not None) and bn is not None and bn_mode == 0 and not defer:
             raise lib.MvpError("a grouped forward with train-mode tap BN must run under the pipeline (its running-statistics updates are per batch)")
 
+        running = [[] for _ in range(G)]  # per batch of the group: its taps' deferred running-statistics updates
+
         def tap(j):
             b = bn[j] if bn is not None else None
             nchw, cls = out["nchw"][j], out["cls"][j]
@@ -419,8 +421,7 @@ class ViTEngine:
                 if want_cls:
                     outs_g[g].cls.append(cls[g])
                 if defer and b is not None and b.get("running_mean") is not None:
-                    st = out["stats"][g, j]
-                    pipeline.defer(lambda st=st, b=b: ops.bn_running_update(st, b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C), group=g)
+                    running[g].append((out["stats"][g, j], b["running_mean"], b["running_var"], b.get("num_batches_tracked"), C))
                 outs_g[g].append(nchw[g])
 
         for i in range(self.depth):
@@ -434,6 +435,8 @@ class ViTEngine:
                 if len(outs_g[0]) == len(layers):
                     break
         for g in range(G):
+            if running[g]:  # all taps of a batch in ONE launch on the consumer's stream (mvp_bn_running_update_n; the modules are distinct)
+                pipeline.defer(lambda items=running[g]: ops.bn_running_update_many(items), group=g)
             outs_g[g].stats = out["stats"][g]
             if packed_g[g] is not None:
                 outs_g[g].packed = packed_g[g]

@@ -29,7 +29,7 @@ def test_info_and_strerror():
     from mvp import lib
 
     inf = lib.info()
-    assert inf.abi_version == 6
+    assert inf.abi_version == 7
     assert lib.load().mvp_strerror(-1).decode().startswith("invalid argument")
 
 
