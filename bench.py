@@ -407,6 +407,8 @@ def main():
                              "HIP streams under the probe steps of the current batches; every step still runs its own full forward + probe "
                              "forward/backward/AdamW inside the timed region, and the pipeline is empty at both of its barriers"}
     pipeline_info["check"] = pipeline_check
+    pipeline_info["probe_step"] = ("tape-free: the autograd path's launches issued without a tape (mvp/fused_step.py; bit-identical trajectories)"
+                                   if getattr(opt, "_mvp_fused_plan", None) not in (None, False) else "autograd tape")
     if pipe.depth > 1 and not args.no_serial_leg:
         serial_pipe = FeaturePipeline(model, 1)
         barrier()
