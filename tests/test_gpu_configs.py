@@ -272,3 +272,34 @@ def test_config5_full_size_properties(dev):
         xy_s, val_s = spair.correspondence(f[0], f[0], kp_c)
     np.testing.assert_array_equal(xy_s.cpu().numpy(), torch.stack(((cells * 49).round().long(), (cells.flip(0) * 49).round().long()), 1).numpy())
     assert float(val_s.min()) > 0.999
+
+
+def test_config5_full_size_features_and_correspondences_vs_oracle(dev):
+    """#5 at its real size against the golden-pinned oracle, not only through properties: iBOT ViT-B/16 (dense, last block) on an
+    800x800 pair — N = 2501 tokens per image, the streaming attention kernel at the longest sequence of BASELINE's configs — within
+    1e-3 rel-L2 of the oracle's features per image (north_star's tolerance on fp32 features), and the 20-keypoint correspondences
+    (evaluate_spair_correspondence.py:45-103) computed by the product from ITS features equal to the oracle's from its own wherever
+    the oracle's best cell leads its runner-up by more than the feature error can move a cosine similarity."""
+    from evals.models.ibot import iBOT
+    from mvp import spair
+    from oracle import spair as ospair, vit as ovit
+
+    vsd = ovit.make_vit_weights(seed=31)
+    g = torch.Generator().manual_seed(32)
+    imgs = torch.randn(2, 3, 800, 800, generator=g)
+    kps = torch.rand(20, 2, generator=g)
+    with torch.no_grad():
+        ref = ovit.vit_dense_features(vsd, imgs, [11], heads=12, add_norm=False)
+        m = iBOT(output="dense", layer=-1, weights=vsd).to(dev)
+        f = m(imgs.to(dev))
+        xy, val = spair.correspondence(f[0], f[1], kps)
+    assert tuple(ref.shape) == tuple(f.shape) == (2, 768, 50, 50)
+    errs = [rel_l2(f[i].cpu().numpy(), ref[i].numpy()) for i in range(2)]
+    print(f"iBOT 800x800 (N=2501) feature rel-L2 per image: {errs[0]:.2e} {errs[1]:.2e}")
+    assert max(errs) < 1e-3
+    pred, heat = ospair.correspondence(ref, kps)
+    top2 = heat.flatten(1).topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3  # cosine similarities: a 1e-3 feature error moves them by less than that
+    assert int(clear.sum()) >= 10
+    np.testing.assert_array_equal(xy.cpu().numpy()[clear.numpy()], pred.numpy()[clear.numpy()])
+    assert rel_l2(val.cpu().numpy(), top2[:, 0].numpy()) < 1e-3

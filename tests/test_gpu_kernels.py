@@ -241,7 +241,7 @@ def _v_third_as_f16_bf16(qp, C):
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_vf16", "bf16"])
-@pytest.mark.parametrize("BNH", [(2, 197, 12), (1, 1201, 3), (3, 25, 2), (2, 64, 1), (1, 129, 2)])
+@pytest.mark.parametrize("BNH", [(2, 197, 12), (1, 1201, 3), (3, 25, 2), (2, 64, 1), (1, 129, 2), (1, 2501, 2)])
 def test_attention(dev, precision, BNH):
     """softmax(Q K^T / 8) V against fp64 (ibot_transformers.py:129-145).  bf16x3_vf16 = the form the ViT engine runs since round 4:
     V as hi fp16 + lo bf16, the probabilities held as ONE fp16 value (2^-12 relative each, averaged over the keys) — the measured error
