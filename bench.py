@@ -684,8 +684,8 @@ def main():
             "dist_backend": backend, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16x3": "bf16x3 (split-bf16 MFMA, three products per contraction, fp32 accumulate; fp32 residual/LN/softmax/loss)",
-                      "f16x2": "f16x2 (compensated fp16 pairs of activations and frozen weights, two f16 MFMA products per contraction, fp32 accumulate, feature error as bf16x3; attention scores, "
-                               "probe, fp32 residual/LN/softmax/loss as in bf16x3)",
+                      "f16x2": "f16x2 (compensated fp16 pairs of activations and frozen weights, two f16 MFMA products per contraction, fp32 accumulate, feature error as bf16x3; attention: Q.K^T "
+                               "the same two products over compensated pairs, P.V fp16 probabilities x (fp16 + bf16) V; probe, fp32 residual/LN/softmax/loss as in bf16x3)",
                       "bf16": "bf16 (MFMA, fp32 accumulate)"}[args.precision],
             "data": "synthetic (randn images, U(0.05,9.95) depth with 10% zeros), random-init ViT-B/16",
             "config": {"workload": f"dino_vitb16 return_multilayer(4 taps, add_norm train-mode BN) {H}x{W} + DepthHead(" + ("linear,k=1" if args.probe == "linear" else "dpt,k=3,hidden512") + f",{args.prediction}) + bilinear upsample + DepthLoss + backward + AdamW + LambdaLR",

@@ -63,7 +63,7 @@ typedef struct {
   int cu_count;         /* multiProcessorCount of device 0                   */
   char arch[64];        /* gcnArchName of device 0                           */
 } mvp_info_t;
-#define MVP_ABI_VERSION 7 /* 7: mvp_bn_running_update_n (a new export; every struct as in 6)
+#define MVP_ABI_VERSION 7 /* 7: mvp_bn_running_update_n (a new export); mvp_gemm_args.out_f16_col0 < -1 and MVP_ATT_V_F16_QK_F16 (new values of existing fields); every struct as in 6
                              6: mvp_gemm_args.out_f16_col0, mvp_attention_args.v_format (both structs grew by one int at the end; zero = the ABI 5 behaviour)
                              5: mvp_upconv3_fwd_gather, mvp_upconv3_grad_boxsum; mvp_gemm_pp accepts conv; depth-loss workspace grew (query mvp_depth_loss_workspace_bytes) */
 int mvp_get_info(mvp_info_t* out);
@@ -174,7 +174,10 @@ typedef struct {
    * out_f16_col0 > 0 (a multiple of 64): columns >= out_f16_col0 are written as hi = fp16(v) (round to nearest even), lo = bf16(v - hi) instead of
    * hi = bf16(v), lo = bf16(v - hi) — the V third of the fused qkv projection (out_f16_col0 = 2 * H * 64), which the attention
    * kernel multiplies with probabilities held as ONE fp16 value (mvp_attention_args.v_format).  Same 2 + 2 bytes, same arrays and
-   * layouts; |v - hi - lo| <= 2^-20 |v|.  Every kernel of mvp_gemm_bias_act_res / mvp_gemm_pp writes it (not stream-K).        */
+   * layouts; |v - hi - lo| <= 2^-20 |v|.  Every kernel of mvp_gemm_bias_act_res / mvp_gemm_pp writes it (not stream-K).
+   * out_f16_col0 = -V0 < -1 (ABI 7; V0 a multiple of 128 = the first column of the V third, 2 * H * 64): the fused qkv projection for
+   * MVP_ATT_V_F16_QK_F16 — columns [0, V0 / 2) (Q) as the compensated activation pair, [V0 / 2, V0) (K) as the compensated WEIGHT-side pair
+   * (hi = fp16((1 - 2^-6) v), lo = fp16((v + 64 d) / 8), d = (1 - 2^-6) v - hi, fp32 arithmetic; hi + lo / 8 = v to ~2^-17), [V0, N) (V) as above. */
   int out_f16_col0;
 } mvp_gemm_args;
 #define MVP_TILES_ALONE 0
@@ -241,6 +244,9 @@ typedef struct {
 } mvp_attention_args;
 #define MVP_ATT_V_BF16_PAIR 0
 #define MVP_ATT_V_F16 1
+#define MVP_ATT_V_F16_QK_F16 2 /* ABI 7.  V and the probabilities as MVP_ATT_V_F16; Q is the compensated ACTIVATION pair and K the compensated WEIGHT-side
+                                  pair of MVP_PREC_F16X2 (mvp_gemm_args.out_f16_col0 = -(first column of the V third)): Q.K^T as two f16 products instead of
+                                  three bf16 ones, same ~2^-18 relative error per term; Q and K must stay within fp16's range (saturating) */
 int mvp_attention_fwd(const mvp_attention_args*, void* stream);
 
 /* ------------------------------------------------------------------------------------

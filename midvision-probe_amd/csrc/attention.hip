@@ -79,7 +79,7 @@ struct AttnState {
 // body is kept lean: raw v_exp_f32 (__builtin_amdgcn_exp2f: no denormal range fix-up, 5 instructions fewer per
 // element; probabilities below 2^-126 are zero either way) and the key-validity mask compiled only into the LAST
 // tile's instantiation.
-template <int SPLIT, bool LAST, bool VF16 = false>
+template <int SPLIT, bool LAST, int VF16 = 0>
 __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, const char* vb, int key0, int N, float cs, int lane) {
   static_assert(!VF16 || SPLIT == 3, "the fp16-probability form belongs to the bf16x3 mode");
   const int g = lane >> 4, c16 = lane & 15;
@@ -100,6 +100,19 @@ __device__ __forceinline__ void attn_tile(AttnState<SPLIT>& st, const char* kb, 
       if (LAST && t >= nsub) continue;
       const char* ka = kb + (t * 16 + c16) * 128 + coff;
       const bf16x8_t k_hi = *(const bf16x8_t*)ka;
+      if (VF16 == 2) {
+        // MVP_ATT_V_F16_QK_F16: Q is the compensated activation pair, K the compensated weight-side pair of MVP_PREC_F16X2 (both written
+        // by the qkv GEMM's epilogue): S^T = k_lo . q_lo + k_hi . q_hi on the f16 MFMA — two products instead of three, in the order
+        // of the GEMM kernels; the sum is q . k + (q - hi_q) . 64 d_k (~2^-18 relative per term: mvp_common.h, split2_f16_comp).
+        const f16x8_t k_lo = *(const f16x8_t*)(ka + TILE);
+        const f16x8_t k_h = __builtin_bit_cast(f16x8_t, k_hi);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_lo, __builtin_bit_cast(f16x8_t, st.q_lo[qt][ks]), s[t][qt], 0, 0, 0);
+          s[t][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k_h, __builtin_bit_cast(f16x8_t, st.q_hi[qt][ks]), s[t][qt], 0, 0, 0);
+        }
+        continue;
+      }
       if (SPLIT == 3) {
         const bf16x8_t k_lo = *(const bf16x8_t*)(ka + TILE);
 #pragma unroll
@@ -312,7 +325,7 @@ __device__ __forceinline__ void attn_stage_piece(const mvp_attention_args& p, si
   }
 }
 
-template <int SPLIT, bool VF16 = false>
+template <int SPLIT, int VF16 = 0>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attention_args p) {
   f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -360,7 +373,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const mvp_attenti
 //   i+1's slot 0, and pair i+1's tiles t >= 1 fall into slots pair i has finished with when the pair-boundary barrier is passed.
 // Per pair: [tile 0 resident, Q in registers] -> issue tiles 1.. (land under tile 0's compute) -> tile 0 -> vmcnt(0) + barrier ->
 // issue next pair's tile 0 + Q -> tiles 1.. -> vmcnt(0) (the prefetch, issued long before) -> output stores -> barrier.
-template <int SPLIT, bool VF16 = false>
+template <int SPLIT, int VF16 = 0>
 __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_attention_args p) {
   f16_saturate_mode();
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(512) void attention_resident_kernel(const mvp_atten
   }
 }
 
-template <int SPLIT, bool VF16 = false>
+template <int SPLIT, int VF16 = 0>
 int launch_attention(const mvp_attention_args* a, hipStream_t s) {
   constexpr int NARR = (SPLIT == 3) ? 2 : 1;
   constexpr int STAGE = 2 * NARR * TILE;
@@ -489,7 +502,8 @@ extern "C" int mvp_attention_fwd(const mvp_attention_args* a, void* stream) {
   if (a->out_layout != MVP_PAIR_SEPARATE && (a->out_layout != MVP_PAIR_A_ILV32 || a->precision != MVP_PREC_BF16X3 || a->ld_out < 2 * a->H * 64)) return MVP_EINVAL;
   if (a->precision == MVP_PREC_BF16X3) {
     if (!a->qkv_lo || (!a->out_lo && a->out_layout == MVP_PAIR_SEPARATE)) return MVP_EINVAL;
-    if (a->v_format == MVP_ATT_V_F16) return launch_attention<3, true>(a, (hipStream_t)stream);
+    if (a->v_format == MVP_ATT_V_F16) return launch_attention<3, 1>(a, (hipStream_t)stream);
+    if (a->v_format == MVP_ATT_V_F16_QK_F16) return launch_attention<3, 2>(a, (hipStream_t)stream);
     if (a->v_format != MVP_ATT_V_BF16_PAIR) return MVP_EINVAL;
     return launch_attention<3>(a, (hipStream_t)stream);
   }

@@ -480,7 +480,7 @@ extern "C" int mvp_gemm_bias_act_res(const mvp_gemm_args* a, void* stream) {
   if (a->pair_layout < 0 || a->pair_layout > MVP_PAIR_ILV32) return MVP_EINVAL;
   if (a->out_pair_layout != MVP_PAIR_SEPARATE &&
       (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31) || (a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2))) return MVP_EINVAL;
-  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < -1 || (a->out_f16_col0 > 0 && (a->out_f16_col0 & 63)) || (a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2) || !a->out_hi ||
+  if (a->out_f16_col0 != 0 && ((a->out_f16_col0 != -1 && ((a->out_f16_col0 < 0 ? -a->out_f16_col0 : a->out_f16_col0) & (a->out_f16_col0 < 0 ? 127 : 63))) || (a->precision != MVP_PREC_BF16X3 && a->precision != MVP_PREC_F16X2) || !a->out_hi ||
                                (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE) || a->splitk > 1))
     return MVP_EINVAL;
   if (a->M > 0 && a->N > 0 && (a->out_f32 || a->out_hi) && pp_takes(a)) return mvp_gemm_pp(a, stream);

@@ -220,12 +220,16 @@ __device__ __forceinline__ void gemm_epilogue(const ARGS& p, f32x4_t (&acc)[NT][
           for (int e = 0; e < 4; ++e) v[e] *= keep[e];  // (out_f32 above stayed un-gated)
         }
         uint32_t h01, l01, h23, l23;
-        if (p.out_f16_col0 < 0) {  // every column as the activation operand of a MVP_PREC_F16X2 GEMM (the compensated fp16 pair)
+        const int form = out_pair_form(p.out_f16_col0, ncol);  // (4 columns: all in one form — every boundary is a multiple of 64)
+        if (form == 2) {  // the activation operand of a MVP_PREC_F16X2 GEMM (the compensated fp16 pair): -1 = every column; the Q third of qkv
           split2_f16_comp(v[0], v[1], h01, l01);
           split2_f16_comp(v[2], v[3], h23, l23);
-        } else if (p.out_f16_col0 != 0 && ncol >= p.out_f16_col0) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv; 4 columns: all in or all out
+        } else if (form == 1) {  // hi = fp16(v), lo = bf16(v - hi): the V third of qkv
           split2_f16_bf16(v[0], v[1], h01, l01);
           split2_f16_bf16(v[2], v[3], h23, l23);
+        } else if (form == 3) {  // the compensated weight-side pair: the K third of qkv for MVP_ATT_QK_F16
+          split2_f16_wcomp(v[0], v[1], h01, l01);
+          split2_f16_wcomp(v[2], v[3], h23, l23);
         } else {
           split2_bf16(v[0], v[1], h01, l01);
           split2_bf16(v[2], v[3], h23, l23);
@@ -315,7 +319,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
   const __amdgpu_buffer_rsrc_t r_bias = rsrc(p.bias), r_res = rsrc(RES ? (const void*)p.residual : nullptr), r_gate = rsrc(GATE ? (const void*)p.relu_mask : nullptr);
   const __amdgpu_buffer_rsrc_t r_o32 = rsrc(F32OUT ? (const void*)p.out_f32 : nullptr), r_ohi = rsrc(PAIR ? (const void*)p.out_hi : nullptr);
   const bool oilv = p.out_pair_layout == MVP_PAIR_A_ILV32;
-  const bool f16_cols = PAIR && p.out_f16_col0 != 0 && (n0 + wn0) >= p.out_f16_col0;  // this wave's 64 columns take the fp16-hi form (-1: every column)
+  const int pform = PAIR ? out_pair_form(p.out_f16_col0, n0 + wn0) : 0;  // the 16-bit form of this wave's 64 columns (wave-uniform)
   const __amdgpu_buffer_rsrc_t r_olo = rsrc(PAIR ? (oilv ? (const void*)p.out_hi : (const void*)p.out_lo) : nullptr);  // interleaved: the lo half sits 64 bytes behind the hi half
   const int lo_soff = oilv ? 64 : 0;
   const int ob = col_ok ? ncol * 4 : SENT;
@@ -404,12 +408,15 @@ __device__ __forceinline__ void gemm_epilogue_wide(const ARGS& p, f32x4_t (&acc)
       }
       if (PAIR) {
         uint32_t hw[4], lw[4];
-        if (p.out_f16_col0 < 0) {  // (-1: every column, the compensated fp16 pair)
+        if (pform == 2) {  // (the compensated fp16 pair: -1 = every column; the Q third of qkv)
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_f16_comp(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
-        } else if (f16_cols) {  // (wave-uniform: out_f16_col0 % 64 == 0)
+        } else if (pform == 1) {  // (the V third)
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_f16_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
+        } else if (pform == 3) {  // (the K third as the weight-side pair)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16_wcomp(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_bf16(v[it][2 * e], v[it][2 * e + 1], hw[e], lw[e]);
@@ -480,7 +487,7 @@ __device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[
   const int lo_soff = oilv ? 64 : 0;
   const bool has_pair = p.out_hi != nullptr;
   const bool nt_pair = has_pair && p.out_f32 == nullptr && p.residual == nullptr && x_rhi == nullptr;  // pair-only form (MVP_EPI_UNI_NT builds)
-  const bool f16_cols = has_pair && p.out_f16_col0 != 0 && (n0 + wn0) >= p.out_f16_col0;  // (wave-uniform: out_f16_col0 % 64 == 0 or -1)
+  const int pform = has_pair ? out_pair_form(p.out_f16_col0, n0 + wn0) : 0;  // (wave-uniform: every boundary is a multiple of 64)
   const int ob = col_ok ? ncol * 4 : SENT;
   const u32x4_t bias_a = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 0, 0), bias_b = __builtin_amdgcn_raw_buffer_load_b128(r_bias, ob, 16, 0);
   const int pcol = oilv ? ilv32_col(ncol) : ncol;
@@ -588,12 +595,15 @@ __device__ __forceinline__ void gemm_epilogue_uni(const ARGS& p, f32x4_t (&acc)[
       __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{f2u(v[it][4]), f2u(v[it][5]), f2u(v[it][6]), f2u(v[it][7])}, r_o32, ro[it].o32, 16, 0);
       uint32_t hw[4] = {0u, 0u, 0u, 0u}, lw[4] = {0u, 0u, 0u, 0u};
       if (has_pair) {
-        if (p.out_f16_col0 < 0) {  // (-1: every column, the compensated fp16 pair)
+        if (pform == 2) {  // (the compensated fp16 pair: -1 = every column; the Q third of qkv)
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_f16_comp(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
-        } else if (f16_cols) {
+        } else if (pform == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_f16_bf16(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
+        } else if (pform == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split2_f16_wcomp(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) split2_bf16(vp[it][2 * e], vp[it][2 * e + 1], hw[e], lw[e]);

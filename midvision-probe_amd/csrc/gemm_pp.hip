@@ -594,7 +594,7 @@ extern "C" int mvp_gemm_pp(const mvp_gemm_args* a, void* stream) {
   if (f16x2 && (a->conv || a->relu_mask || a->out_mask || a->residual2 || a->act_after_res || a->residual_hi)) return MVP_EINVAL;
   if (!a->out_f32 && !a->out_hi) return MVP_EINVAL;
   if (a->out_pair_layout != MVP_PAIR_SEPARATE && (a->out_pair_layout != MVP_PAIR_A_ILV32 || !a->out_hi || (a->N & 31))) return MVP_EINVAL;
-  if (a->out_f16_col0 != 0 && (a->out_f16_col0 < -1 || (a->out_f16_col0 > 0 && (a->out_f16_col0 & 63)) || !a->out_hi || (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE))) return MVP_EINVAL;
+  if (a->out_f16_col0 != 0 && ((a->out_f16_col0 != -1 && ((a->out_f16_col0 < 0 ? -a->out_f16_col0 : a->out_f16_col0) & (a->out_f16_col0 < 0 ? 127 : 63))) || !a->out_hi || (!a->out_lo && a->out_pair_layout == MVP_PAIR_SEPARATE))) return MVP_EINVAL;
   // 32-bit per-lane byte offsets: 256 tile rows of the widest supported row must stay below 2 GiB
   if ((int64_t)256 * a->lda * 2 >= 0x7fffff00ll || (int64_t)256 * a->ldw * 2 >= 0x7fffff00ll) return MVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;

@@ -80,6 +80,35 @@ __device__ __forceinline__ void split2_f16_comp(float a, float b, uint32_t& hi, 
   const f16x2_t l = __builtin_convertvector(f32x2v_t{f16_clamp(la), f16_clamp(lb)}, f16x2_t);
   lo = __builtin_bit_cast(uint32_t, l);
 }
+// The WEIGHT-side operand of MVP_PREC_F16X2 computed on the device in fp32 (the K third of qkv for MVP_ATT_QK_F16): hi = fp16((1 - 2^-6) v),
+// lo = fp16((v + 64 d) / 8), d = (1 - 2^-6) v - hi.  hi rounds the fp32 product (2^-24: far below the pair's 2^-18) to 11 bits; d is one fma on the
+// exact product; v / 8 is exact and the second fma rounds once.  hi + lo / 8 reproduces v to ~2^-17.
+__device__ __forceinline__ void split2_f16_wcomp(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const float ta = a * 0.984375f, tb = b * 0.984375f;
+  const f16x2_t h = __builtin_convertvector(f32x2v_t{f16_clamp(ta), f16_clamp(tb)}, f16x2_t);
+  hi = __builtin_bit_cast(uint32_t, h);
+  // d from the EXACT product (one fma, one rounding) — written out so that no build's contraction choice decides the bits
+  const float da = __builtin_fmaf(a, 0.984375f, -(float)h[0]), db = __builtin_fmaf(b, 0.984375f, -(float)h[1]);
+  const float la = __builtin_fmaf(da, 8.f, a * 0.125f), lb = __builtin_fmaf(db, 8.f, b * 0.125f);
+  const f16x2_t l = __builtin_convertvector(f32x2v_t{f16_clamp(la), f16_clamp(lb)}, f16x2_t);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+// Which 16-bit pair form column `col` of a GEMM's pair output takes (mvp_gemm_args.out_f16_col0; wave-uniform wherever col is a wave tile's
+// first column: every boundary is a multiple of 64): 0 = bf16 pair, 1 = fp16 hi + bf16 lo (V), 2 = compensated activation pair, 3 = compensated
+// weight pair.  out_f16_col0 = -2C' (< -1, C' = 2 * heads * 64 = the V third's first column): Q | K | V = forms 2 | 3 | 1.
+__device__ __forceinline__ int out_pair_form(int f16_col0, int col) {
+  if (f16_col0 == 0) return 0;
+  if (f16_col0 == -1) return 2;
+  if (f16_col0 > 0) return col >= f16_col0 ? 1 : 0;
+  const int v0 = -f16_col0;
+  return col >= v0 ? 1 : (col >= (v0 >> 1) ? 3 : 2);
+}
+__device__ __forceinline__ void split2_form(int form, float a, float b, uint32_t& hi, uint32_t& lo) {
+  if (form == 2) split2_f16_comp(a, b, hi, lo);
+  else if (form == 1) split2_f16_bf16(a, b, hi, lo);
+  else if (form == 3) split2_f16_wcomp(a, b, hi, lo);
+  else split2_bf16(a, b, hi, lo);
+}
 // Output stores of data that this kernel never reads back and the NEXT kernel reads once (operand pairs): MVP_OUT_NT 1 marks them non-temporal
 // (global_store ... nt), so they do not push the operands of the running kernel out of L2.  Per kernel: MVP_LN_NT, MVP_ATT_NT (A/B builds).
 template <class T>

@@ -298,16 +298,19 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: Pai
 
 
 def attention(qkv: Pair, out: Pair, B: int, N: int, H: int, scale: float, precision: int, ld_qkv=None, ld_out=None, v_f16: bool = False,
-              out_f16: bool = False) -> None:
+              out_f16: bool = False, qk_f16: bool = False) -> None:
     """``v_f16``: the V third of ``qkv`` holds hi = fp16, lo = bf16 (``gemm(..., f16_col0=2 * H * 64)``); the probabilities are then held
     as one fp16 value (mvp_attention_args.v_format = MVP_ATT_V_F16; bf16x3 only).  ``out_f16``: the output pair leaves as the activation
-    operand of a PREC_F16X2 GEMM (``split_f16_comp``'s form)."""
+    operand of a PREC_F16X2 GEMM (``split_f16_comp``'s form).  ``qk_f16`` (with ``v_f16``): Q and K are the compensated fp16 pairs of
+    ``gemm(..., f16_col0=-2 * H * 64)`` (activation / weight-side form) and Q.K^T runs two f16 products (MVP_ATT_V_F16_QK_F16)."""
+    if qk_f16 and not v_f16:
+        raise lib.MvpError("attention: qk_f16 needs v_f16 (mvp_attention_args.v_format = MVP_ATT_V_F16_QK_F16)")
     ilv = isinstance(out, IlvPair)
     if ilv:
         out, ld_out = (out.t, None), (ld_out if ld_out is not None else 2 * H * 64)
     a = lib.AttentionArgs(lib.ptr(qkv[0]), lib.ptr(qkv[1]), lib.ptr(out[0]), lib.ptr(out[1]), B, N, H,
                           ld_qkv if ld_qkv is not None else 3 * H * 64, ld_out if ld_out is not None else H * 64, scale, precision,
-                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE, 1 if v_f16 else 0, 1 if out_f16 else 0)
+                          lib.PAIR_A_ILV32 if ilv else lib.PAIR_SEPARATE, (2 if qk_f16 else 1) if v_f16 else 0, 1 if out_f16 else 0)
     if _TRACE is None:
         lib.call("mvp_attention_fwd", a)
         return

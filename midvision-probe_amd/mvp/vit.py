@@ -78,6 +78,7 @@ _PACK_REGISTRY: Dict[int, PackedFeatures] = {}
 # one entry per (pipeline slot, forward shape, batch of the forward): a span pipeline keeps 2 slots x two shapes (floor / ceil of T / B
 # whole batches) x up to 14 batches = 54 entries at B = 8, and a model has a train and an eval pipeline; a graph replay re-registers
 # its packings (pipeline._forward), so an entry that ages out anyway comes back at its forward's next replay
+ATT_QK_DEFAULT = "auto"  # MVP_ATT_QK: "f16" = Q.K^T in two f16 products (ViTEngine.att_qk_f16), "pair" = three bf16 products, "auto" = f16 for f16x2 engines
 _PACK_REGISTRY_MAX = 256
 
 
@@ -128,6 +129,12 @@ class ViTEngine:
             self.precision = PREC_BF16X3
         self.heads, self.patch, self.ln_eps = heads, patch, ln_eps
         self.att_v_f16 = self.precision == lib.PREC_BF16X3 and os.environ.get("MVP_ATT_V", "f16") != "pair"
+        # Q.K^T as TWO f16 products over compensated fp16 pairs (Q: activation form, K: weight-side form, both written by the qkv GEMM's
+        # epilogue; csrc/attention.hip, VF16 == 2) instead of three bf16 ones; MVP_ATT_QK=pair brings the bf16 pairs back
+        # Default: on for an f16x2 engine (whose activations are bound to fp16's range anyway), off for bf16x3 (which keeps fp32's exponent
+        # range for Q and K).  +0.4 % at 224^2, +1.3 % at 480x640 (profiles/r04_qk_ab.txt); the reference's goldens read the same 1.5e-5 ... 2.4e-5.
+        qk = os.environ.get("MVP_ATT_QK", ATT_QK_DEFAULT)
+        self.att_qk_f16 = self.att_v_f16 and (qk == "f16" or (qk == "auto" and self.f16x2))
         self.check_f16_range = os.environ.get("MVP_CHECK_F16_RANGE", "0") == "1"  # diagnostic: see _check_f16_range
         self.pos_embed_mode = pos_embed_mode
         sd = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in state_dict.items()}
@@ -294,10 +301,14 @@ class ViTEngine:
         # bf16x3: the V third of qkv leaves the GEMM as hi = fp16, lo = bf16, and the attention kernel holds its probabilities as one
         # fp16 value (csrc/attention.hip, VF16; MVP_ATT_V=pair brings back the bf16-pair probabilities of rounds 1-3)
         vf16 = self.att_v_f16
-        # (f16x2: Q and K stay bf16 pairs — Q.K^T keeps its three products —, the attention output, LayerNorm's and fc1's output leave as compensated fp16 activation pairs)
+        # (f16x2: Q and K leave as compensated fp16 pairs too — activation / weight-side form, Q.K^T in two f16 products — unless MVP_ATT_QK=pair;
+        #  the attention output, LayerNorm's and fc1's output leave as compensated fp16 activation pairs)
+        qk16 = self.att_qk_f16
         ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out=ws["qkv"], precision=gp, w_ilv=blk.get("qkv_w_ilv"),
-                 f16_col0=2 * C if vf16 else 0)
-        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16, out_f16=f2)
+                 f16_col0=(-2 * C if qk16 else 2 * C) if vf16 else 0)
+        if chk and qk16:
+            self._check_f16_range(f"block {i}: Q / K", (ws["qkv"][0][:, :2 * C], ws["qkv"][1][:, :2 * C]), M)
+        ops.attention(ws["qkv"], ws["ao"], B, N, self.heads, 64 ** -0.5, pr, v_f16=vf16, qk_f16=qk16, out_f16=f2)
         if chk:
             self._check_f16_range(f"block {i}: attention output", ws["ao"], M)
         ops.gemm(ws["ao"], blk["proj_w"], M, C, C, bias=blk["proj_b"], residual=x, out_f32=x, precision=gp, w_ilv=blk.get("proj_w_ilv"))

@@ -240,7 +240,31 @@ def _v_third_as_f16_bf16(qp, C):
     return hi, lo
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_vf16", "bf16"])
+def _wcomp_pair(y):
+    """The compensated WEIGHT-side pair as the qkv GEMM's epilogue computes it (csrc/mvp_common.h, split2_f16_wcomp; fp32 arithmetic):
+    hi = fp16(fp32((1 - 2^-6) y)), d = fma(y, 1 - 2^-6, -hi), lo = fp16(fma(d, 8, y / 8)) — each fma stated in fp64 (exact there) and rounded once."""
+    y = y.float()
+    hi = (y * 0.984375).clamp(-65504.0, 65504.0).half()
+    d = (y.double() * 0.984375 - hi.double()).float()                  # fma(y, 1 - 2^-6, -hi): exact in fp64, one rounding to fp32
+    lo = (d.double() * 8.0 + y.double() * 0.125).float().clamp(-65504.0, 65504.0).half()  # fma(d, 8, y / 8)
+    return hi.view(torch.bfloat16), lo.view(torch.bfloat16)
+
+
+def _qk_thirds_as_f16_comp(qp, C):
+    """Q third -> compensated activation pair, K third -> compensated weight-side pair (mvp_gemm_args.out_f16_col0 = -2C), V as given."""
+    from mvp import ops
+
+    hi, lo = qp[0].clone(), qp[1].clone()
+    q = qp[0][:, :C].float() + qp[1][:, :C].float()
+    k = qp[0][:, C:2 * C].float() + qp[1][:, C:2 * C].float()
+    qh, ql = ops.split_f16_comp(q)
+    kh, kl = _wcomp_pair(k)
+    hi[:, :C], lo[:, :C] = qh, ql
+    hi[:, C:2 * C], lo[:, C:2 * C] = kh, kl
+    return hi, lo
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_vf16", "bf16x3_vf16_qk16", "bf16"])
 @pytest.mark.parametrize("BNH", [(2, 197, 12), (1, 1201, 3), (3, 25, 2), (2, 64, 1), (1, 129, 2), (1, 2501, 2)])
 def test_attention(dev, precision, BNH):
     """softmax(Q K^T / 8) V against fp64 (ibot_transformers.py:129-145).  bf16x3_vf16 = the form the ViT engine runs since round 4:
@@ -250,8 +274,9 @@ def test_attention(dev, precision, BNH):
     from mvp.vit import parse_precision
 
     B, N, H = BNH
-    vf16 = precision.endswith("_vf16")
-    pr = parse_precision(precision.replace("_vf16", ""))
+    qk16 = precision.endswith("_qk16")  # Q.K^T as two f16 products over compensated fp16 pairs (MVP_ATT_V_F16_QK_F16): same bound as vf16
+    vf16 = "_vf16" in precision
+    pr = parse_precision(precision.replace("_qk16", "").replace("_vf16", ""))
     C = H * 64
     g = torch.Generator().manual_seed(N)
     qkv = torch.randn(B * N, 3 * C, generator=g)
@@ -260,13 +285,15 @@ def test_attention(dev, precision, BNH):
     qp = ops.split_bf16(qd, pr)
     if vf16:
         qp = _v_third_as_f16_bf16(qp, C)
+    if qk16:
+        qp = _qk_thirds_as_f16_comp(qp, C)
     src = (_bf16_round(qkv) if pr == lib.PREC_BF16 else qkv).double()
     t = src.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     att = ((t[0] @ t[1].transpose(-2, -1)) * 0.125).softmax(-1)
     ref = (att @ t[2]).transpose(1, 2).reshape(B * N, C)
     out = ops.empty_pair((B * N, C), lib.PREC_BF16X3, dev)
     out[0].fill_(float("nan")); out[1].fill_(float("nan"))
-    ops.attention(qp, out, B, N, H, 0.125, pr, v_f16=vf16)
+    ops.attention(qp, out, B, N, H, 0.125, pr, v_f16=vf16, qk_f16=qk16)
     torch.cuda.synchronize()
     got = (out[0].float() + out[1].float()).cpu()
     assert torch.isfinite(got).all()
@@ -470,6 +497,17 @@ def test_vit_base_224_vs_reference_golden(dev, precision, tol):
     print(f"\n[vit_base {precision}] rel-L2 (tap, raw) per layer:", errs)
     for e_t, e_r in errs:
         assert e_t < tol and e_r < tol
+
+
+@pytest.mark.parametrize("qk", ["pair", "f16"])
+def test_vit_goldens_with_either_form_of_q_and_k(dev, monkeypatch, qk):
+    """MVP_ATT_QK: Q.K^T as three bf16 products over bf16 pairs ("pair") or as two f16 products over compensated fp16 pairs ("f16":
+    Q / K written in that form by the qkv GEMM's epilogue, ibot_transformers.py:129-145) — whichever is the default, BOTH hold the reference's
+    ViT-B/16 goldens (224^2 and 480x640, f16x2 and bf16x3 GEMMs) to the 1e-3 feature contract; the measured errors are printed."""
+    monkeypatch.setenv("MVP_ATT_QK", qk)
+    for precision in ("f16x2", "bf16x3"):
+        test_vit_base_224_vs_reference_golden(dev, precision, 1e-3)
+        test_vit_base_480x640_vs_reference_golden(dev, precision)
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
@@ -793,6 +831,51 @@ def test_f16_pairs_saturate_instead_of_overflowing(dev):
     assert big.any() and torch.isfinite(hi).all() and torch.isfinite(lo).all() and hi.abs().max().item() == 65504.0
     assert ((hi + lo - av).abs()[big] / av.abs()[big]).max().item() < 2 ** -8
     assert ((hi + lo - av).abs()[~big] / av.abs()[~big].clamp_min(1e-3)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+def test_qkv_epilogue_writes_q_k_v_in_their_attention_forms(dev, prec):
+    """mvp_gemm_args.out_f16_col0 = -2C (the fused qkv projection for MVP_ATT_V_F16_QK_F16): the Q third leaves as the compensated
+    activation pair, the K third as the compensated weight-side pair, the V third as fp16 hi + bf16 lo — each bit for bit the torch statement
+    of its form applied to the fp32 output of the same GEMM, from the large-M kernel (tile loop, ragged last row tile) and from the tile kernels
+    alike (serial loop = pipelined loop), and hi + lo / 8 of the K third returns the value to 2^-16."""
+    from mvp import lib, ops
+
+    M, C, K = 17000, 256, 128  # 67 x 3 tiles of 256 x 256 > 256 CUs: the persistent tile loop runs; N = 3C = 768
+    g = torch.Generator().manual_seed(77)
+    a = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(3 * C, K, generator=g) * 0.3).to(dev)
+    bias = torch.randn(3 * C, generator=g).to(dev)
+    if prec == "f16x2":
+        ap, wp, pr = ops.split_f16_comp(a), tuple(t.to(dev) for t in ops.f16x2_weight(w)), lib.PREC_F16X2
+    else:
+        ap, wp, pr = ops.split_bf16(a), ops.split_bf16(w), lib.PREC_BF16X3
+    import ctypes as CT
+
+    so, outs = lib.load(), {}
+    N = 3 * C
+    for fam in ("pp", "tiles"):
+        o32 = torch.empty(M, N, device=dev)
+        op = ops.empty_pair((M, N), lib.PREC_BF16X3, dev)
+        for f32 in (True, False):
+            args = lib.GemmArgs(lib.ptr(ap[0]), lib.ptr(ap[1]), lib.ptr(wp[0]), lib.ptr(wp[1]), lib.ptr(bias), None, lib.ptr(o32) if f32 else None,
+                                None if f32 else lib.ptr(op[0]), None if f32 else lib.ptr(op[1]), M, N, K, K, K, N, N, N, lib.ACT_NONE, pr, 0, 0, 0, 0)
+            args.tile_policy = lib.TILES_NO_PP if fam == "tiles" else 0
+            args.out_f16_col0 = 0 if f32 else -2 * C
+            lib.check((so.mvp_gemm_bias_act_res if fam == "tiles" else so.mvp_gemm_pp)(CT.byref(args), lib.stream_ptr()), fam)
+        torch.cuda.synchronize()
+        outs[fam] = (o32, op)
+    (y, (hi, lo)), (y2, (hi2, lo2)) = outs["pp"], outs["tiles"]
+    assert torch.equal(y, y2) and torch.equal(hi, hi2) and torch.equal(lo, lo2)
+    qh, ql = ops.split_f16_comp(y[:, :C])
+    assert torch.equal(hi[:, :C], qh) and torch.equal(lo[:, :C], ql)
+    kh, kl = _wcomp_pair(y[:, C:2 * C])
+    assert torch.equal(hi[:, C:2 * C], kh) and torch.equal(lo[:, C:2 * C], kl)
+    vh = y[:, 2 * C:].half()
+    assert torch.equal(hi[:, 2 * C:], vh.view(torch.bfloat16)) and torch.equal(lo[:, 2 * C:], (y[:, 2 * C:] - vh.float()).bfloat16())
+    kv = y[:, C:2 * C]
+    rec = kh.view(torch.float16).float() + kl.view(torch.float16).float() / 8
+    assert ((rec - kv).abs() / kv.abs().clamp_min(1e-2)).max().item() < 2 ** -16
 
 
 def test_layernorm_and_attention_interleaved_outputs_match_separate(dev):

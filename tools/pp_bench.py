@@ -29,6 +29,7 @@ def build_ablate(n, define="MVP_PP_ABLATE", tag="ab"):
     so = os.path.join(REPO, "tools", "micro", f"libpp_{tag}{n}.so")
     if not os.path.exists(so):
         fl = subprocess.run(["make", "-s", "-C", CS, "print-cxxflags"], capture_output=True, text=True, check=True).stdout.strip()
+        fl += " " + subprocess.run(["make", "-s", "-C", CS, "print-ppflags"], capture_output=True, text=True, check=True).stdout.strip()  # gemm_pp.hip's own
         fl = fl.replace("-I../../include", f"-I{REPO}/include")
         cmd = f"set -o pipefail; /opt/rocm/bin/hipcc {fl} -shared -I{CS} -D{define}={n} -w {CS}/gemm_pp.hip -o {so} 2>&1 | {{ grep -v 'recognized feature' || true; }}"
         subprocess.run(["bash", "-c", cmd], check=True)
