@@ -18,8 +18,8 @@ class DINO(bb.ViTBackbone):
         feat_dims = {"vitb8": 768, "vitb16": 768, "vitb14": 768, "vitb14_reg": 768, "vitl14": 1024, "vitg14": 1536}
         if dino_name != "dino" or model_name != "vitb16":
             raise NotImplementedError("the HIP path covers DINO ViT-B/16 (configs/backbone/dino_b16.yaml)")
-        if return_kqv:
-            raise NotImplementedError("return_kqv is outside the hot path")
+        if return_kqv and mode_selected not in ("k", "q", "v", "kqv"):
+            raise ValueError(f"mode_selected {mode_selected!r}: one of k, q, v, kqv (dino.py:126-139)")
         self.arch = "vit"
         self.return_cls = return_cls
         self.dino_name, self.model_name = dino_name, model_name
@@ -50,6 +50,8 @@ class DINO(bb.ViTBackbone):
         self.set_precision(precision or bb.default_precision())
 
     def forward(self, images):
+        if self.return_kqv:  # dino.py:164-169
+            return self.extract_kqv(self.preprocess_image(images)[0])
         if len(self.multilayers) == 1 and self.return_cls:
             # dino.py:206-207: embeds[0][:, 0] — the (tap-BN normalised when add_norm) CLS token of the single tap
             return self._extract(images, want_cls=True).cls[0]

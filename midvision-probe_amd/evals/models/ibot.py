@@ -21,8 +21,8 @@ class iBOT(bb.ViTBackbone):
         model_dict = {"base": "ibot_vitb16", "base_in22k": "ibot_vitb16_in22k"}
         if model_type not in model_dict:
             raise NotImplementedError("the HIP path covers iBOT ViT-B/16 (model_type base / base_in22k)")
-        if return_kqv:
-            raise NotImplementedError("return_kqv is outside the hot path")
+        if return_kqv and mode_selected not in ("k", "q", "v", "kqv"):
+            raise ValueError(f"mode_selected {mode_selected!r}: one of k, q, v, kqv (ibot.py:169-180)")
         ckpt_name = model_dict[model_type]
         sd = weights
         if sd is None:  # reference: urlretrieve + torch.load(...)["state_dict"] (ibot.py:46-56)
@@ -44,6 +44,8 @@ class iBOT(bb.ViTBackbone):
         self.set_precision(precision or bb.default_precision())
 
     def forward(self, images):
+        if self.return_kqv:  # ibot.py:182-186
+            return self.extract_kqv(self.preprocess_image(images)[0])
         if len(self.multilayers) == 1 and self.return_cls:
             # ibot.py:199-200: raw CLS token of the tapped block (no BN, no later blocks)
             eng = self.engine()

@@ -227,6 +227,34 @@ class ViTBackbone(nn.Module):
             # (num_batches_tracked is incremented by the tap kernel's statistics pass: no extra launch)
         return taps
 
+    def extract_kqv(self, images):
+        """dino.py:82-139, ibot.py:128-180 (the same code in both wrappers): K / Q / V of the last attention layer (the output of its fused qkv projection), CLS row dropped,
+        as [B, C, h*w] ("kqv": [B, 3C, h*w], k | q | v).  No centre padding on this path (the reference calls prepare_tokens directly;
+        ``fixed_size`` is a multiple of the patch size in every config)."""
+        if images.ndim == 3:
+            images = images.unsqueeze(0)
+        if images.ndim == 5:
+            images = images.squeeze(0)
+        if not images.is_cuda:
+            raise lib.MvpError("images must be on the HIP device (no CPU fallback)")
+        if images.shape[-2] % self.patch_size or images.shape[-1] % self.patch_size:
+            raise ValueError("extract_kqv: the image size must be a multiple of the patch size (dino.py:105 has no padding on this path)")
+        with torch.no_grad():
+            qkv = self.engine().last_block_qkv(images)
+        bs, _, C3 = qkv.shape
+        C = C3 // 3
+        hw = (images.shape[-2] // self.patch_size) * (images.shape[-1] // self.patch_size)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        pick = {"k": [k], "q": [q], "v": [v], "kqv": [k, q, v]}[self.mode_selected]
+        return torch.cat([t[:, 1:].transpose(1, 2).reshape(bs, C, hw) for t in pick], dim=1)
+
+    def preprocess_image(self, rgb_image):
+        """dino.py:141-161, ibot.py:102-124: torchvision ``Resize((fixed_size, fixed_size))`` of a [C,H,W] / [B,C,H,W] tensor (bilinear, antialiased)."""
+        from . import functional as MF
+
+        x = rgb_image if rgb_image.ndim == 4 else rgb_image.unsqueeze(0)
+        return MF.resize_antialias(x, (self.fixed_size, self.fixed_size)), self.fixed_size // self.patch_size, self.fixed_size // self.patch_size
+
     def _finish(self, taps: TapOutputs):
         """tokens_to_output (evals/models/utils.py:105-124) per tap.  'dense' is the kernel's own output; 'cls' is the
         (tap-normalised) CLS token the tap kernel emits next to the map; 'gap' / 'dense-cls' are shape glue on those.

@@ -454,6 +454,22 @@ class ViTEngine:
                 register_pack(outs_g[g], packed_g[g])
         return outs_g[0] if (G == 1 and span is None) else TapGroups(outs_g)
 
+    def last_block_qkv(self, images: torch.Tensor) -> torch.Tensor:
+        """The fused qkv projection of the LAST block (fp32 [B, N, 3C]: q | k | v, heads side by side) — what the reference captures
+        with a forward hook on ``blocks[-1].attn.qkv`` (dino.py:82-113).  Blocks 0 .. depth-2 run as usual; the last block stops after
+        LayerNorm 1 and the projection (its attention output is never used on that path)."""
+        ws, B, gh, gw = self.tokens(images)
+        N = 1 + gh * gw
+        for i in range(self.depth - 1):
+            self.run_block(i, ws, B, N)
+        blk, C, M = self.blocks[self.depth - 1], self.C, B * N
+        f2 = self.f16x2
+        ops.layernorm(ws["x"], blk["n1w"], blk["n1b"], ws["xn"], M, C, self.ln_eps, out_f16=f2)
+        out = torch.empty(M, 3 * C, dtype=torch.float32, device=self.device)
+        ops.gemm(ws["xn"], blk["qkv_w"], M, 3 * C, C, bias=blk["qkv_b"], out_f32=out, precision=lib.PREC_F16X2 if f2 else self.precision,
+                 w_ilv=blk.get("qkv_w_ilv"))
+        return out.view(B, N, 3 * C)
+
     def forward_tokens(self, images: torch.Tensor, n_blocks: Optional[int] = None) -> torch.Tensor:
         """Raw fp32 token stream after ``n_blocks`` blocks ([B, N, C]); for tests / CLS outputs."""
         ws, B, gh, gw = self.tokens(images)

@@ -280,3 +280,33 @@ def vit_dense_features(
     n_sp = h * w
     outs = [tokens_to_output(output, t[:, -n_sp:], t[:, 0], (h, w)) for t in taps]
     return outs[0] if len(outs) == 1 else outs
+
+
+def last_block_qkv(sd: StateDict, images: torch.Tensor, heads: int = 12, patch: int = 16, eps: float = 1e-6, pos_mode: str = "dino"):
+    """DINO.extract_kqv, dino.py:82-131 — what the forward hook on ``blocks[-1].attn.qkv`` captures: the fused qkv projection of the
+    last block's pre-normalised input, after all earlier blocks (no centre padding on this path: dino.py:105 calls prepare_tokens
+    directly).  Returns (q, k, v) as [B, N, C] each (heads merged back: dino.py:117-124)."""
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    x = prepare_tokens(sd, images, patch, pos_mode)
+    for i in range(depth - 1):
+        x = block(sd, i, x, heads, eps)
+    p = f"blocks.{depth - 1}."
+    C = x.shape[-1]
+    y = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd.get(p + "attn.qkv.bias"))
+    B, N, _ = qkv.shape
+    qkv = qkv.reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    return tuple(t.transpose(1, 2).reshape(B, N, C) for t in (qkv[0], qkv[1], qkv[2]))
+
+
+def dino_kqv_features(sd: StateDict, images: torch.Tensor, fixed_size: int, mode: str = "k", heads: int = 12, patch: int = 16) -> torch.Tensor:
+    """DINO.forward with return_kqv=True, dino.py:82-168: torchvision ``Resize((fixed, fixed))`` (bilinear, antialias: the default for
+    tensors in the pinned torchvision 0.17.1) -> extract_kqv -> the selected projection(s) without the CLS row as [B, C (3C), h*w]."""
+    if images.ndim == 3:
+        images = images[None]
+    x = F.interpolate(images.float(), size=(fixed_size, fixed_size), mode="bilinear", align_corners=False, antialias=True)
+    q, k, v = last_block_qkv(sd, x, heads, patch)
+    B, _, C = k.shape
+    hw = (fixed_size // patch) ** 2
+    pick = {"k": [k], "q": [q], "v": [v], "kqv": [k, q, v]}[mode]
+    return torch.cat([t[:, 1:].transpose(1, 2).reshape(B, C, hw) for t in pick], dim=1)

@@ -322,3 +322,27 @@ def test_spair_evaluate_dataset(dev):
     assert abs(recall - (errs < 0.10).float().mean().item() * 100.0) < 1e-9
     assert conf.sum().item() == errs.numel() and 0.0 <= recall <= 100.0
     assert sorted(spair.shard_pairs(5, 0, 2) + spair.shard_pairs(5, 1, 2)) == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("mode", ["k", "q", "v", "kqv"])
+def test_dino_return_kqv_vs_oracle(dev, mode):
+    """DINO(return_kqv=True) (dino.py:82-169): antialiased Resize to fixed_size, all blocks but the last, then the last block's fused qkv
+    projection (what the reference's forward hook captures), CLS dropped, [B, C (3C), h*w]; a [C,H,W] image and a batch alike."""
+    from evals.models.dino import DINO
+    from oracle import vit as ovit
+
+    sd = _weights(61)
+    m = DINO(return_kqv=True, fixed_size=96, mode_selected=mode, weights=sd).to(dev)
+    g = torch.Generator().manual_seed(4)
+    batch = torch.rand(2, 3, 150, 200, generator=g)
+    out = m(batch.to(dev))
+    ref = ovit.dino_kqv_features(sd, batch, 96, mode, heads=HEADS)
+    assert tuple(out.shape) == tuple(ref.shape) == (2, (3 if mode == "kqv" else 1) * D, 36)
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-3
+    one = m(batch[0].to(dev))  # a single [C,H,W] image (dino.py:91-92)
+    assert tuple(one.shape) == (1, ref.shape[1], 36) and rel_l2(one[0].cpu().numpy(), ref[0].numpy()) < 1e-3
+    if mode == "k":  # the same path in the iBOT wrapper (ibot.py:128-186)
+        from evals.models.ibot import iBOT
+
+        mi = iBOT(return_kqv=True, fixed_size=96, mode_selected="k", weights=sd).to(dev)
+        assert rel_l2(mi(batch.to(dev)).cpu().numpy(), ref.numpy()) < 1e-3
