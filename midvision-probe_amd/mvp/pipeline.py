@@ -652,12 +652,13 @@ def cached_pipelines(model) -> dict:
 
 
 def pipelined_features(model, batches: Iterable, image_key="image", depth: int = None, probe=None, group: int = None,
-                       pipe: "FeaturePipeline" = None) -> Iterator[Tuple[object, object]]:
+                       pipe: "FeaturePipeline" = None, graphs: bool = None) -> Iterator[Tuple[object, object]]:
     """Yield ``(batch, features)`` for every batch of ``batches`` with up to ``depth`` forwards in flight: the forwards of the next
     batches are enqueued before batch t is handed to the caller, so they run under the caller's probe step t.  ``depth`` None:
     ``default_depth(probe)``.  Consecutive equal-shaped batches are stacked ``group`` at a time into one forward (None:
     ``default_group``; an epoch's ragged last batch and whatever is left over run as smaller forwards).  ``pipe``: an existing
-    pipeline to reuse (its captured graphs); it must be empty."""
+    pipeline to reuse (its captured graphs); it must be empty.  ``graphs``: handed to ``FeaturePipeline`` (None: its default — off for
+    jobs with more than one rank; a loop with NO collective in flight, e.g. the sharded SPair evaluation, passes True)."""
     if pipe is None:
         hint = None
         if depth is None:
@@ -670,12 +671,12 @@ def pipelined_features(model, batches: Iterable, image_key="image", depth: int =
         # graphs the first one captured (setting a pipeline's graphs up costs ~0.25 s: a tenth of an NYU-sized epoch at this throughput).
         # A cached pipeline that is still in use (a loop suspended mid-epoch) is left alone: the caller gets a fresh one.
         cache = cached_pipelines(model)
-        key = (bool(getattr(model, "training", False)), depth, group, hint)
+        key = (bool(getattr(model, "training", False)), depth, group, hint) + (() if graphs is None else (bool(graphs),))
         pipe = cache.get(key)
         if pipe is None or len(pipe) or pipe._open or pipe._lent:
             # (the cached pipeline refers to its model weakly: the map's values must not keep its keys alive)
             keep = cache is not _NO_CACHE
-            pipe = FeaturePipeline(weakref.proxy(model) if keep else model, depth, group=group, ungrouped_depth=hint)
+            pipe = FeaturePipeline(weakref.proxy(model) if keep else model, depth, group=group, ungrouped_depth=hint, graphs=graphs)
             if keep:
                 cache[key] = pipe
         pipe._lent = True

@@ -134,8 +134,15 @@ def evaluate_dataset(model, dataset, thresh, verbose=False, rank: int = 0, world
             kp_dev = ring.to_device((kps_i[:, :2].contiguous(),), images.device)[0]
             yield {"image": images, "meta": (i, kps_i, kps_j, thresh_scale, kp_dev)}
 
+    # Jobs with more than one rank launch their forwards eagerly by default (mvp/pipeline.py: a lazy graph capture is a device-wide sync
+    # that must not land beside a pending all-reduce).  This loop has NO collective in flight — the one exchange is the
+    # all_gather_object after it — so it keeps hipGraph replay at any world size (eager launches: 48-80 pairs/s against 115-148 at
+    # 800^2, profiles/r04_fullsize_configs.txt); MVP_PIPELINE_GRAPHS still wins when set.
+    import os
+
+    graphs = True if (world > 1 and os.environ.get("MVP_PIPELINE_GRAPHS") is None) else None
     pending = []
-    for b, feats in pipelined_features(model, pairs()):
+    for b, feats in pipelined_features(model, pairs(), graphs=graphs):
         f = torch.cat(list(feats), dim=1) if isinstance(feats, (list, tuple)) else feats
         i, kps_i, kps_j, thresh_scale, kp_dev = b["meta"]
         pred_xy, _ = correspondence(f[0], f[1], kp_dev)

@@ -13,7 +13,7 @@ for p in (REPO, os.path.join(REPO, "midvision-probe_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-D, DEPTH, PAIRS, SIZE, KPS = 128, 4, 7, 160, 9
+D, DEPTH, PAIRS, SIZE, KPS = 128, 4, 19, 160, 9
 
 
 def build(dev):
@@ -36,9 +36,14 @@ def main():
 
     rank, local, world = mdist.env_setup("nccl")
     dev = torch.device("cuda", torch.cuda.current_device())
-    recall, conf = spair.evaluate_dataset(build(dev), dataset(), 0.10, rank=rank, world=world)
+    from mvp import pipeline
+
+    model = build(dev)
+    recall, conf = spair.evaluate_dataset(model, dataset(), 0.10, rank=rank, world=world)
+    pipes = list(pipeline.cached_pipelines(model).values())
     np.savez(os.path.join(out_dir, f"spair{rank}.npz"), recall=np.float64(recall), conf=conf.numpy(), world=world,
-             backend=np.array(torch.distributed.get_backend()))
+             backend=np.array(torch.distributed.get_backend()), graphs=np.array([p.graphs for p in pipes]), depth=np.array([p.depth for p in pipes]),
+             replays=np.array([sum(max(0, e["calls"] - 1) for e in p._graphs.values() if e.get("graph") is not None) for p in pipes]))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -117,7 +117,8 @@ def test_spair_pair_sharding_two_ranks_equals_single_process(tmp_path):
     """BASELINE config #5 shards image PAIRS over the ranks (evaluate_spair_correspondence.py:104-121 is the single loop):
     two ranks (gloo, one shared card) each evaluate pairs r, r + 2, ... through their own forward pipeline, gather the per-pair error /
     index vectors with one all_gather_object and re-sort them into dataset order — every rank must return exactly what one process
-    returns for the whole dataset (recall and confusion matrix, bit for bit; 7 pairs: uneven shards)."""
+    returns for the whole dataset (recall and confusion matrix, bit for bit; 19 pairs: uneven shards), with its forwards replaying captured
+    hipGraphs (no collective is in flight inside that loop, so it keeps graph replay at any world size)."""
     import _spair_rank as S
     from mvp import spair
 
@@ -127,7 +128,8 @@ def test_spair_pair_sharding_two_ranks_equals_single_process(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   MVP_DIST_BACKEND="gloo", MVP_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+                   MVP_DIST_BACKEND="gloo", MVP_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2",
+                   MVP_INFLIGHT="2", MVP_PIPELINE_GROUP="2")  # two forwards (of two pairs) in flight per rank: the sharded loop keeps hipGraph replay at world > 1 (mvp/spair.py)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_spair_rank.py"), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         try:
@@ -142,6 +144,7 @@ def test_spair_pair_sharding_two_ranks_equals_single_process(tmp_path):
         assert int(got["world"]) == 2 and str(got["backend"]) == "gloo"
         assert float(got["recall"]) == recall
         np.testing.assert_array_equal(got["conf"], conf.numpy())
+        assert got["graphs"].all() and (got["depth"] == 2).all() and int(got["replays"].sum()) >= 1, (got["graphs"], got["depth"], got["replays"])
     assert conf.sum().item() > 0 and 0.0 <= recall <= 100.0
 
 
